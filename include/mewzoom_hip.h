@@ -1,0 +1,143 @@
+/*
+ * mewzoom_hip.h — C ABI of libmewzoom_hip.so: the MI355X (gfx950) implementation of the
+ * MewZoom upscale path of andrewdalpino/UltraZoom v0.3.0.
+ *
+ * The reference has no FFI / plugin interface of its own: its boundary for this path is the Python
+ * API of `MewZoom` (src/ultrazoom/model.py:43-192).  Each entry point below names the reference
+ * interface it stands in for; INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success or a negative mz_status code and
+ *     never throws; mz_last_error() returns a thread-local human-readable message.
+ *   - all `dev` pointers are device (HBM) pointers owned by the CALLER (PyTorch-ROCm allocates
+ *     them).  The library borrows them for the duration of the call and only keeps its own packed
+ *     copy of the weights (allocated in mz_set_weight, freed in mz_destroy).
+ *   - compute calls enqueue work on the given HIP stream and never synchronise; a handle must not
+ *     be used from two threads at once.
+ *   - images are NCHW, contiguous, element type = the handle's dtype, values nominally in [0, 1]
+ *     (README.md:72-79 of the reference).
+ */
+#ifndef MEWZOOM_HIP_H
+#define MEWZOOM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mz_handle mz_handle;
+
+typedef enum mz_dtype {
+    MZ_F32 = 0,  /* exact f32 MFMA (v_mfma_f32_32x32x2_f32): the 1e-3 max-abs verification mode */
+    MZ_BF16 = 1, /* bf16 storage + v_mfma_f32_32x32x16_bf16, f32 accumulate and f32 epilogues  */
+    MZ_F16 = 2   /* fp16 storage + v_mfma_f32_32x32x16_f16,  f32 accumulate and f32 epilogues  */
+} mz_dtype;
+
+typedef enum mz_status {
+    MZ_OK = 0,
+    MZ_ERR_INVALID_ARGUMENT = -1, /* the reference raises AssertionError for these (model.py:67-69, 218-222, 265-275, 738) */
+    MZ_ERR_UNKNOWN_WEIGHT = -2,
+    MZ_ERR_SHAPE_MISMATCH = -3,
+    MZ_ERR_MISSING_WEIGHTS = -4,
+    MZ_ERR_WORKSPACE_TOO_SMALL = -5,
+    MZ_ERR_HIP = -6,
+    MZ_ERR_NO_DEVICE = -7
+} mz_status;
+
+/* The 11 constructor kwargs of MewZoom.__init__ (model.py:51-64), verbatim. */
+typedef struct mz_config {
+    int32_t upscale_ratio;
+    int32_t primary_channels;
+    int32_t primary_layers;
+    int32_t secondary_channels;
+    int32_t secondary_layers;
+    int32_t tertiary_channels;
+    int32_t tertiary_layers;
+    int32_t quaternary_channels;
+    int32_t quaternary_layers;
+    int32_t hidden_ratio;
+    int32_t num_deg_features;
+} mz_config;
+
+/* ---- lifetime: replaces MewZoom.__init__ (model.py:51-92) -------------------------------- */
+
+/* Validates the configuration exactly as the reference constructor does (same rejected values)
+ * and creates a handle that will compute in `dtype`.  Touches no GPU. */
+int mz_create(const mz_config* cfg, int dtype, mz_handle** out);
+int mz_destroy(mz_handle* h);
+
+/* ---- weights: replaces load_state_dict / PyTorchModelHubMixin.from_pretrained (model.py:37,43;
+ *      SURVEY.md appendix B for the key names) ---------------------------------------------- */
+
+/* Number of state_dict entries the model has, and the name / shape of entry i.
+ * `shape` receives up to 4 dims; returns ndim (0 for the scalar `alpha`s). */
+int mz_num_weights(const mz_handle* h);
+int mz_weight_info(const mz_handle* h, int index, const char** name, int64_t shape[4]);
+
+/* Hands one BAKED parameter (plain conv.weight / bias / alpha — no weight-norm or LoRA
+ * parametrisation left, test_compare.py:32-45) to the library.  `dev_f32` points at a contiguous
+ * float32 device tensor in the reference layout (OIHW for conv weights).  The library packs it
+ * into MFMA-fragment order in the handle's dtype on the given stream; the caller may free its
+ * tensor once the stream has passed this call. */
+int mz_set_weight(mz_handle* h, const char* name, const float* dev_f32, const int64_t* shape, int ndim,
+                  void* hip_stream);
+
+/* 0 when every parameter has been set, else MZ_ERR_MISSING_WEIGHTS (message lists the first one). */
+int mz_weights_complete(const mz_handle* h);
+
+/* ---- the hot path: replaces MewZoom.forward / upscale / predict_degredation
+ *      (model.py:149-164, 166-179, 181-192) -------------------------------------------------- */
+
+/* Bytes of scratch HBM a call with this batch/shape needs.  The library processes the batch in
+ * micro-batches of at most `max_images_in_flight` images (0 = library default), so memory does
+ * not grow beyond that. */
+int mz_workspace_bytes(const mz_handle* h, int B, int H, int W, int max_images_in_flight, size_t* bytes);
+
+/* x        [B,3,H,W]      input, handle dtype
+ * out_sr   [B,3,rH,rW]    s + head(unet(stem(x))) (model.py:162); clamped to [0,1] when clamp != 0
+ *                         (model.py:177), NULL to skip nothing — must be non-NULL
+ * out_qa   [B,F] float32  degradation features z_qa (model.py:159,1026-1032), or NULL to skip the
+ *                         quality head (upscale() discards it, model.py:175)
+ */
+int mz_forward(mz_handle* h, const void* x, void* out_sr, float* out_qa, int B, int H, int W, int clamp,
+               void* workspace, size_t workspace_bytes, int max_images_in_flight, void* hip_stream);
+
+/* ---- single operators, exported for the parity tests (tests/test_ops_gpu.py) ---------------
+ * These run the SAME kernels mz_forward launches, on caller-provided tensors.
+ * Activation tensors here are the library's internal layout: NHWC with the channel count padded
+ * to a multiple of 16, element type = dtype.  mz_padded_channels(c) gives that count. */
+int mz_padded_channels(int c);
+
+/* kind: 0 conv3x3 pad1 (+SiLU when silu!=0)            w: [cout,cin,3,3]    out [B,H,W,cout_p]
+ *       1 conv3x3 + PixelShuffle(2) into [B,Hout,Wout,cout/4] (zero-filled beyond 2H,2W)
+ *       2 PixelCrush conv2x2 stride2                   w: [cout,cin,2,2]    out [B,H/2,W/2,cout_p]
+ *       3 AdaptiveResidualMix(in0, in1)                w: [c,2c,1,1], alpha out [B,H,W,c_p]
+ */
+int mz_op_conv(int dtype, int kind, const void* in0, const void* in1, const float* w_dev_f32, float alpha,
+               void* out, int B, int H, int W, int cin, int cout, int Hout, int Wout, int silu,
+               void* hip_stream);
+/* stem: NCHW image -> NHWC features (model.py:239-242) */
+int mz_op_stem(int dtype, const void* x, const float* w_dev_f32, const float* b_dev_f32, void* out, int B,
+               int H, int W, int cout, void* hip_stream);
+/* final: conv3x3 (cin -> 12) + PixelShuffle(2) + bicubic(img, R) + add [+ clamp] -> NCHW image
+ * feat [B,H,W,cin_p]; img [B,3,H*2/R,W*2/R]; out [B,3,2H,2W]  (model.py:926-930, 156, 162, 177) */
+int mz_op_final(int dtype, const void* feat, const void* img, const float* w_dev_f32, void* out, int B, int H,
+                int W, int cin, int R, int clamp, void* hip_stream);
+
+/* ---- introspection ------------------------------------------------------------------------ */
+const char* mz_last_error(void);
+const char* mz_version(void);
+/* Algorithmic FLOPs (2 x conv MACs) of one forward on an H x W image. */
+double mz_flops_per_image(const mz_handle* h, int H, int W);
+/* Enables per-kernel HIP-event timing for bench.py's live roofline leg: after a forward, returns the
+ * accumulated device time (ms) and FLOPs of all conv3x3 implicit-GEMM launches since the last reset. */
+int mz_profile_enable(mz_handle* h, int on);
+int mz_profile_read(mz_handle* h, double* conv_ms, double* conv_flops, double* conv_launches,
+                    double* other_ms, double* conv_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEWZOOM_HIP_H */

@@ -87,8 +87,8 @@ def parameter_shapes(cfg: dict) -> Dict[str, Tuple[int, ...]]:
     def block(prefix: str, c: int) -> None:
         shapes[f"{prefix}.convnet.conv1.weight"] = (hr * c, c, 3, 3)  # model.py:742-744
         shapes[f"{prefix}.convnet.conv2.weight"] = (c, hr * c, 3, 3)  # model.py:746-748
+        shapes[f"{prefix}.skip.alpha"] = ()  # model.py:807 (a module's own parameters precede its children's)
         shapes[f"{prefix}.skip.conv.weight"] = (c, 2 * c, 1, 1)  # model.py:805
-        shapes[f"{prefix}.skip.alpha"] = ()  # model.py:807
 
     c0 = ch[0]
     shapes["stem.conv.weight"] = (c0, 3, 1, 1)  # model.py:224
@@ -110,8 +110,10 @@ def parameter_shapes(cfg: dict) -> Dict[str, Tuple[int, ...]]:
     for d in range(3):
         cin, cout = ch[3 - d], ch[2 - d]
         shapes[f"unet.decoder.upsample{d + 1}.conv.weight"] = (4 * cout, cin, 3, 3)  # :569-571,900-909
-        shapes[f"unet.decoder.skip{d + 1}.conv.weight"] = (cout, 2 * cout, 1, 1)  # :573-575
+    for d in range(3):
+        cout = ch[2 - d]
         shapes[f"unet.decoder.skip{d + 1}.alpha"] = ()
+        shapes[f"unet.decoder.skip{d + 1}.conv.weight"] = (cout, 2 * cout, 1, 1)  # :573-575
 
     n_head = int(log2(cfg["upscale_ratio"]))  # model.py:945
     for i in range(n_head):

@@ -1,0 +1,70 @@
+"""CPU-side checks of the C ABI: the library loads without a GPU, exports every declared symbol,
+validates configurations like the reference, and describes the model's parameters correctly."""
+
+import ctypes
+import json
+import re
+from pathlib import Path
+
+import pytest
+
+from golden_util import GOLDEN, MODEL_CASES, GoldenCase
+from oracle import mewzoom_oracle as oracle
+from ultrazoom_amd import _ffi
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    header = (REPO / "include" / "mewzoom_hip.h").read_text()
+    declared = set(re.findall(r"\b(mz_[a-z0-9_]+)\s*\(", header))
+    declared -= {"mz_handle", "mz_config", "mz_dtype", "mz_status"}
+    assert len(declared) >= 15
+    lib = ctypes.CDLL(str(_ffi.LIB_PATH))
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/mewzoom_hip.h but not exported"
+
+
+def test_create_rejects_what_the_reference_rejects():
+    trials = json.loads((GOLDEN / "validation.json").read_text())
+    for name, t in trials.items():
+        if t["raises"] is None:
+            _ffi.Handle(t["kwargs"], _ffi.MZ_F32).close()
+        else:
+            with pytest.raises(_ffi.MewZoomHipError) as ei:
+                _ffi.Handle(t["kwargs"], _ffi.MZ_F32)
+            assert ei.value.code == _ffi.MZ_ERR_INVALID_ARGUMENT, name
+
+
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_weight_registry_matches_reference_state_dict(name):
+    case = GoldenCase(name)
+    for dt in (_ffi.MZ_F32, _ffi.MZ_BF16):
+        h = _ffi.Handle(case.config, dt)
+        infos = h.weight_infos()
+        assert [k for k, _ in infos] == list(case.meta["shapes"])
+        assert {k: list(v) for k, v in infos} == case.meta["shapes"]
+        h.close()
+
+
+def test_flops_and_workspace():
+    case = GoldenCase("g7_cfg1_2x_c48")
+    h = _ffi.Handle(case.config, _ffi.MZ_BF16)
+    assert abs(h.flops_per_image(256, 256) - oracle.flops_per_image(case.config, 256, 256)) < 1.0
+    assert abs(h.flops_per_image(540, 960) - oracle.flops_per_image(case.config, 540, 960)) < 1.0
+    w1 = h.workspace_bytes(1, 256, 256)
+    w4 = h.workspace_bytes(4, 256, 256, 4)
+    w4_1 = h.workspace_bytes(4, 256, 256, 1)
+    assert 0 < w1 == w4_1 < w4 <= 4 * w1 + 65536
+    with pytest.raises(_ffi.MewZoomHipError):
+        h.workspace_bytes(1, 4, 4)
+    h.close()
+
+
+def test_unknown_weight_and_missing_weights_fail_loudly():
+    case = GoldenCase("g1_2x_c16")
+    h = _ffi.Handle(case.config, _ffi.MZ_F32)
+    with pytest.raises(_ffi.MewZoomHipError) as ei:
+        h.weights_complete()
+    assert "has not been set" in str(ei.value)
+    h.close()

@@ -1,0 +1,74 @@
+"""Host-side behaviour of the drop-in MewZoom class (no GPU): parameter tree, HF round trip,
+constructor validation, checkpoint baking, and the refusal to compute without an MI355X."""
+
+import json
+
+import pytest
+import torch
+
+from golden_util import GOLDEN, GoldenCase
+from ultrazoom_amd import MewZoom, bake_state_dict
+from ultrazoom_amd.synth import synth_state_dict
+
+
+def test_state_dict_layout_matches_reference():
+    for name in ("g1_2x_c16", "g3_4x_c16", "g4_8x_c16", "g5_layers_3254", "g8_c24_f5"):
+        case = GoldenCase(name)
+        m = MewZoom(**case.config)
+        sd = m.state_dict()
+        assert list(sd) == list(case.meta["shapes"])
+        assert {k: list(v.shape) for k, v in sd.items()} == case.meta["shapes"]
+        assert m.num_params == case.meta["num_params"]
+        assert m.upscale_ratio == case.config["upscale_ratio"]
+        m.load_state_dict(case.weights())  # strict
+
+
+def test_constructor_raises_like_the_reference():
+    trials = json.loads((GOLDEN / "validation.json").read_text())
+    for name, t in trials.items():
+        if t["raises"] is None:
+            MewZoom(**t["kwargs"])
+        else:
+            with pytest.raises(AssertionError):
+                MewZoom(**t["kwargs"])
+
+
+def test_hf_round_trip(tmp_path):
+    case = GoldenCase("g1_2x_c16")
+    m = MewZoom(**case.config)
+    m.load_state_dict(case.weights())
+    m.save_pretrained(tmp_path)
+    cfg = json.loads((tmp_path / "config.json").read_text())
+    assert {k: cfg[k] for k in case.config} == case.config
+    m2 = MewZoom.from_pretrained(tmp_path)
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+
+
+def test_no_cpu_fallback():
+    case = GoldenCase("g1_2x_c16")
+    m = MewZoom(**case.config)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        m.upscale(case.image())
+    with pytest.raises(RuntimeError, match="MI355X"):
+        m.forward(case.image())
+
+
+def test_bake_weight_norm_checkpoint():
+    case = GoldenCase("g1_2x_c16")
+    sd = case.weights()
+    raw = {}
+    for k, v in sd.items():
+        if k.endswith("conv.weight") or k.endswith("conv1.weight") or k.endswith("conv2.weight"):
+            base = k[: -len(".weight")]
+            norm = v.flatten(1).norm(dim=1).reshape(-1, 1, 1, 1)
+            raw["_orig_mod." + base + ".parametrizations.weight.original0"] = norm.clone()
+            raw["_orig_mod." + base + ".parametrizations.weight.original1"] = v * 3.0  # direction only
+        else:
+            raw["_orig_mod." + k] = v
+    baked = bake_state_dict(raw)
+    assert set(baked) == set(sd)
+    for k in sd:
+        assert torch.allclose(baked[k], sd[k], atol=1e-6), k
+    m = MewZoom(**case.config)
+    m.load_training_checkpoint(raw)

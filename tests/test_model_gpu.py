@@ -1,0 +1,158 @@
+"""Whole-model parity on a real MI355X through the drop-in MewZoom class (=> the C ABI => the HIP kernels).
+
+Gates
+  float32 : max-abs <= 1e-3 against the reference's own outputs (the golden fixtures) — the bar
+            BASELINE.json's north_star states; the f32 MFMA path lands around 1e-5.
+  bf16/f16: reduced-precision storage cannot meet 1e-3 through 20-40 layers (the reference's own bf16
+            differs from its fp32 by 7e-3 max-abs / 56.6 dB), so these are gated on
+            PSNR (data range 1.0, as pretrain.py:209) and a looser max-abs, both written below.
+"""
+
+import os
+
+import pytest
+import torch
+
+from golden_util import MODEL_CASES, GoldenCase, psnr
+from oracle import mewzoom_oracle as oracle
+from ultrazoom_amd import MewZoom
+from ultrazoom_amd.synth import synth_image, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 1e-3
+LOWP = {
+    torch.bfloat16: dict(max_abs=0.12, psnr=40.0, qa=0.05),
+    torch.float16: dict(max_abs=0.02, psnr=55.0, qa=0.01),
+}
+
+
+def build(case_or_cfg, weights, dtype):
+    cfg = case_or_cfg.config if isinstance(case_or_cfg, GoldenCase) else case_or_cfg
+    m = MewZoom(**cfg)
+    m.load_state_dict(weights)
+    return m.to("cuda", dtype).eval()
+
+
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_golden_f32(name):
+    case = GoldenCase(name)
+    m = build(case, case.weights(), torch.float32)
+    x = case.image().cuda()
+    sr, qa = m.forward(x)
+    up = m.upscale(x)
+    errs = case.compare_sr(sr, up)
+    qa_err = (qa.float().cpu() - torch.from_numpy(case.data["qa"])).abs().max().item()
+    print(f"{name}: f32 max-abs sr {errs['sr']:.3e} up {errs['up']:.3e} qa {qa_err:.3e}")
+    assert errs["sr"] <= F32_TOL and errs["up"] <= F32_TOL and qa_err <= F32_TOL
+    assert up.min().item() >= 0.0 and up.max().item() <= 1.0
+    assert torch.equal(m.predict_degredation(x), qa)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_golden_low_precision(name, dtype):
+    case = GoldenCase(name)
+    gate = LOWP[dtype]
+    m = build(case, case.weights(), dtype)
+    x = case.image().to("cuda", dtype)
+    with torch.inference_mode():
+        want_sr, want_qa = oracle.forward(case.config, case.weights(), case.image())
+    sr, qa = m.forward(x)
+    up = m.upscale(x)
+    assert sr.dtype == dtype and up.dtype == dtype and qa.dtype == dtype
+    err = (sr.float().cpu() - want_sr).abs().max().item()
+    p = psnr(up.float().cpu(), want_sr.clamp(0, 1))
+    qa_err = (qa.float().cpu() - want_qa).abs().max().item()
+    print(f"{name}: {dtype} max-abs {err:.3e} PSNR {p:.1f} dB qa {qa_err:.3e}")
+    assert err <= gate["max_abs"] and p >= gate["psnr"] and qa_err <= gate["qa"]
+
+
+def test_staging_paths_agree_bit_for_bit():
+    """LDS-DMA (global_load_lds) staging and register staging must produce identical bits."""
+    case = GoldenCase("g2_odd_37x45")
+    x = case.image().to("cuda", torch.bfloat16)
+    outs = []
+    for flag in ("1", "0"):
+        os.environ["MZ_USE_GLDS"] = flag
+        try:
+            m = build(case, case.weights(), torch.bfloat16)
+            outs.append(m.forward(x)[0])
+        finally:
+            os.environ.pop("MZ_USE_GLDS", None)
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_batch_independence_and_micro_batching():
+    case = GoldenCase("g9_4x_c32")
+    m = build(case, case.weights(), torch.bfloat16)
+    x = synth_image(5, 40, 56, 77).to("cuda", torch.bfloat16)
+    full = m.upscale(x)
+    again = m.upscale(x)
+    assert torch.equal(full, again), "the path must be deterministic"
+    m.max_images_in_flight = 2
+    chunked = m.upscale(x)
+    assert torch.equal(full, chunked)
+    for b in (0, 3, 4):
+        assert torch.equal(m.upscale(x[b : b + 1]), full[b : b + 1])
+
+
+CFG2 = dict(upscale_ratio=2, primary_channels=48, primary_layers=4, secondary_channels=96, secondary_layers=4,
+            tertiary_channels=192, tertiary_layers=4, quaternary_channels=384, quaternary_layers=8, hidden_ratio=2,
+            num_deg_features=3)
+CFG3 = dict(upscale_ratio=4, primary_channels=96, primary_layers=8, secondary_channels=192, secondary_layers=8,
+            tertiary_channels=384, tertiary_layers=8, quaternary_channels=768, quaternary_layers=16, hidden_ratio=2,
+            num_deg_features=3)
+
+
+def test_cfg2_full_size_540p_against_oracle():
+    """BASELINE config 2 geometry (2X, 48ch/20 layers, 540x960 -> 1080p; 540/8 is not an integer, so every
+    floor / zero-pad path runs) on ONE image, f32 and bf16, against the CPU oracle at full size."""
+    sd = synth_state_dict(oracle.parameter_shapes(CFG2), 21)
+    x = synth_image(1, 540, 960, 22)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    with torch.inference_mode():
+        want = oracle.upscale(CFG2, sd, x)
+    m = build(CFG2, sd, torch.float32)
+    got = m.upscale(x.cuda()).cpu()
+    err = (got - want).abs().max().item()
+    print(f"cfg2 540p f32: max-abs {err:.3e}")
+    assert err <= F32_TOL
+    mb = build(CFG2, sd, torch.bfloat16)
+    gb = mb.upscale(x.to("cuda", torch.bfloat16)).float().cpu()
+    p = psnr(gb, want)
+    print(f"cfg2 540p bf16: max-abs {(gb - want).abs().max().item():.3e} PSNR {p:.1f} dB")
+    assert p >= 40.0
+
+
+def test_cfg3_model_reduced_size_against_oracle_and_full_size_properties():
+    """BASELINE config 3 model (4X, 96ch/40 layers, 434 M parameters).  The oracle needs minutes per 1080p
+    image on CPU, so: direct parity at 1/16 of the pixels, then size-independent properties at 1080p."""
+    sd = synth_state_dict(oracle.parameter_shapes(CFG3), 31)
+    x = synth_image(1, 136, 240, 32)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    with torch.inference_mode():
+        want = oracle.upscale(CFG3, sd, x)
+    m = build(CFG3, sd, torch.float32)
+    err = (m.upscale(x.cuda()).cpu() - want).abs().max().item()
+    print(f"cfg3 model 136x240 f32: max-abs {err:.3e}")
+    assert err <= F32_TOL
+    del m
+    torch.cuda.empty_cache()
+    mb = build(CFG3, sd, torch.bfloat16)
+    p = psnr(mb.upscale(x.to("cuda", torch.bfloat16)).float().cpu(), want)
+    print(f"cfg3 model 136x240 bf16: PSNR {p:.1f} dB")
+    assert p >= 40.0
+    # full 1080p -> 8K: two different images; each must equal its own single-image run, bit for bit,
+    # and the clamp must hold everywhere
+    xb = synth_image(2, 1080, 1920, 33).to("cuda", torch.bfloat16)
+    mb.max_images_in_flight = 2
+    both = mb.upscale(xb)
+    assert both.shape == (2, 3, 4320, 7680)
+    assert both.min().item() >= 0.0 and both.max().item() <= 1.0
+    mb.max_images_in_flight = 1
+    assert torch.equal(mb.upscale(xb[1:2]), both[1:2])
+    # the bicubic skip dominates the output: it must correlate with a plain bicubic upscale of the input
+    ref_bic = oracle.bicubic_upsample(xb[0:1, :, :64, :64].float().cpu(), 4).clamp(0, 1)
+    got = both[0:1, :, : 64 * 4 - 16, : 64 * 4 - 16].float().cpu()
+    assert (got - ref_bic[..., : 64 * 4 - 16, : 64 * 4 - 16]).abs().mean().item() < 0.2

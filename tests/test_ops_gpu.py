@@ -1,0 +1,180 @@
+"""Operator-level parity on a real MI355X: every kernel mz_forward launches, called through the C ABI
+on its own, against the CPU oracle (torch CPU float32) on the same inputs.  Inputs and weights are
+rounded to the compute dtype first, so what is measured is the kernel's arithmetic."""
+
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import DTYPES, OP_TOL, from_nhwc, op_conv, pad16, q, stream_ptr, to_nhwc
+from oracle import mewzoom_oracle as oracle
+from ultrazoom_amd import _ffi
+from ultrazoom_amd.synth import hash_uniform
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(shape, seed, scale=1.0):
+    n = 1
+    for s in shape:
+        n *= s
+    return torch.from_numpy(((2.0 * hash_uniform(n, seed) - 1.0) * scale).reshape(shape))
+
+
+def wrnd(shape, seed):
+    fan_in = shape[1] * shape[2] * shape[3]
+    return rnd(shape, seed, (3.0 / fan_in) ** 0.5 * 1.7)
+
+
+CONV_CASES = [
+    # B, H, W, cin, cout, silu
+    (1, 8, 32, 16, 32, 0),
+    (2, 13, 37, 16, 48, 1),    # ragged tile edges, N=48 -> padded tile
+    (1, 20, 70, 48, 96, 1),    # NT=3, 3 K-chunks
+    (1, 9, 33, 24, 40, 0),     # channel counts that need padding to 16
+    (1, 16, 40, 32, 128, 1),   # two N tiles
+    (1, 5, 9, 160, 16, 0),     # long K, tiny image
+    (3, 8, 8, 96, 192, 1),     # BASELINE cfg3 stage-1 channel shape, batch > 1
+    (1, 17, 65, 192, 96, 0),
+]
+
+
+@pytest.mark.parametrize("dt", list(DTYPES))
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3x3(dt, case):
+    dtype = DTYPES[dt]
+    B, H, W, cin, cout, silu = case
+    x = q(rnd((B, cin, H, W), 1), dtype)
+    w = q(wrnd((cout, cin, 3, 3), 2), dtype)
+    out = torch.full((B, H, W, pad16(cout)), 7.0, dtype=dtype, device="cuda")
+    op_conv(dtype, 0, to_nhwc(x, dtype), None, w, 0.0, out, B, H, W, cin, cout, silu=silu)
+    want = F.conv2d(x, w, padding=1)
+    if silu:
+        want = F.silu(want)
+    got = from_nhwc(out, cout)
+    err = (got - want).abs().max().item()
+    assert err < OP_TOL[dt], f"max-abs {err}"
+    if pad16(cout) > cout:
+        assert out[..., cout:].abs().max().item() == 0.0, "pad channels must be written as zeros"
+
+
+D2S_CASES = [
+    # B, H, W, cin, cout(=4*cq), Hout, Wout
+    (1, 7, 9, 32, 64, 14, 18),
+    (2, 5, 6, 16, 96, 11, 13),    # cq = 24 -> padded to 32; target one larger: zero border
+    (1, 9, 35, 64, 128, 19, 70),
+    (1, 8, 32, 96, 384, 16, 64),  # head C -> 4C of cfg3
+]
+
+
+@pytest.mark.parametrize("dt", list(DTYPES))
+@pytest.mark.parametrize("case", D2S_CASES)
+def test_subpixel_conv(dt, case):
+    dtype = DTYPES[dt]
+    B, H, W, cin, cout, Hout, Wout = case
+    cq = cout // 4
+    x = q(rnd((B, cin, H, W), 3), dtype)
+    w = q(wrnd((cout, cin, 3, 3), 4), dtype)
+    out = torch.full((B, Hout, Wout, pad16(cq)), 7.0, dtype=dtype, device="cuda")
+    op_conv(dtype, 1, to_nhwc(x, dtype), None, w, 0.0, out, B, H, W, cin, cout, Hout, Wout)
+    want = oracle.fit_to(oracle.subpixel_conv(x, w), (Hout, Wout))
+    got = from_nhwc(out, cq)
+    err = (got - want).abs().max().item()
+    assert err < OP_TOL[dt], f"max-abs {err}"
+    if pad16(cq) > cq:
+        assert out[..., cq:].abs().max().item() == 0.0
+
+
+CRUSH_CASES = [(2, 7, 9, 16, 32), (1, 16, 64, 48, 96), (1, 21, 19, 24, 40), (1, 34, 66, 96, 192), (1, 9, 40, 192, 384)]
+
+
+@pytest.mark.parametrize("dt", list(DTYPES))
+@pytest.mark.parametrize("case", CRUSH_CASES)
+def test_pixel_crush(dt, case):
+    dtype = DTYPES[dt]
+    B, H, W, cin, cout = case
+    x = q(rnd((B, cin, H, W), 5), dtype)
+    w = q(wrnd((cout, cin, 2, 2), 6), dtype)
+    out = torch.full((B, H // 2, W // 2, pad16(cout)), 7.0, dtype=dtype, device="cuda")
+    op_conv(dtype, 2, to_nhwc(x, dtype), None, w, 0.0, out, B, H, W, cin, cout)
+    want = F.conv2d(x, w, stride=2)
+    err = (from_nhwc(out, cout) - want).abs().max().item()
+    assert err < OP_TOL[dt], f"max-abs {err}"
+
+
+MIX_CASES = [(2, 7, 9, 16), (1, 16, 17, 24), (1, 20, 33, 48), (2, 8, 40, 96), (1, 5, 13, 128), (1, 3, 50, 384)]
+
+
+@pytest.mark.parametrize("dt", list(DTYPES))
+@pytest.mark.parametrize("case", MIX_CASES)
+def test_adaptive_residual_mix(dt, case):
+    dtype = DTYPES[dt]
+    B, H, W, c = case
+    x = q(rnd((B, c, H, W), 7), dtype)
+    z = q(rnd((B, c, H, W), 8), dtype)
+    w = q(wrnd((c, 2 * c, 1, 1), 9), dtype)
+    alpha = 0.37
+    out = torch.full((B, H, W, pad16(c)), 7.0, dtype=dtype, device="cuda")
+    op_conv(dtype, 3, to_nhwc(x, dtype), to_nhwc(z, dtype), w, alpha, out, B, H, W, 2 * c, c)
+    want = oracle.residual_mix(x, z, w, torch.tensor(alpha))
+    err = (from_nhwc(out, c) - want).abs().max().item()
+    assert err < OP_TOL[dt], f"max-abs {err}"
+    if pad16(c) > c:
+        assert out[..., c:].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("dt", list(DTYPES))
+@pytest.mark.parametrize("case", [(2, 9, 11, 16), (1, 33, 40, 48), (1, 8, 8, 24)])
+def test_stem(dt, case):
+    dtype = DTYPES[dt]
+    B, H, W, c = case
+    x = q(rnd((B, 3, H, W), 10).abs(), dtype)
+    w = rnd((c, 3, 1, 1), 11)
+    b = rnd((c,), 12, 0.1)
+    out = torch.full((B, H, W, pad16(c)), 7.0, dtype=dtype, device="cuda")
+    xd, wd, bd = x.to("cuda", dtype).contiguous(), w.cuda(), b.cuda()
+    _ffi.check(_ffi.lib().mz_op_stem(
+        _ffi.dtype_code(dtype), ctypes.c_void_p(xd.data_ptr()), ctypes.c_void_p(wd.data_ptr()),
+        ctypes.c_void_p(bd.data_ptr()), ctypes.c_void_p(out.data_ptr()), B, H, W, c, ctypes.c_void_p(stream_ptr())))
+    torch.cuda.synchronize()
+    want = F.conv2d(x, w, b)
+    err = (from_nhwc(out, c) - want).abs().max().item()
+    assert err < OP_TOL[dt], f"max-abs {err}"
+    if pad16(c) > c:
+        assert out[..., c:].abs().max().item() == 0.0
+
+
+FINAL_CASES = [
+    # B, H, W (conv grid), cin, R, clamp
+    (1, 8, 32, 16, 2, 0),
+    (2, 9, 11, 16, 2, 1),
+    (1, 20, 36, 48, 4, 1),
+    (1, 16, 24, 32, 8, 0),
+    (1, 10, 70, 96, 4, 1),
+]
+
+
+@pytest.mark.parametrize("dt", list(DTYPES))
+@pytest.mark.parametrize("case", FINAL_CASES)
+def test_final_subpixel_bicubic_add_clamp(dt, case):
+    dtype = DTYPES[dt]
+    B, H, W, cin, R, clamp = case
+    Hi, Wi = 2 * H // R, 2 * W // R
+    assert Hi * R == 2 * H and Wi * R == 2 * W
+    feat = q(rnd((B, cin, H, W), 13), dtype)
+    img = q(rnd((B, 3, Hi, Wi), 14).abs(), dtype)
+    w = q(wrnd((12, cin, 3, 3), 15) * 0.5, dtype)
+    out = torch.full((B, 3, 2 * H, 2 * W), 7.0, dtype=dtype, device="cuda")
+    fd, imd, wd = to_nhwc(feat, dtype), img.to("cuda", dtype).contiguous(), w.cuda()
+    _ffi.check(_ffi.lib().mz_op_final(
+        _ffi.dtype_code(dtype), ctypes.c_void_p(fd.data_ptr()), ctypes.c_void_p(imd.data_ptr()),
+        ctypes.c_void_p(wd.data_ptr()), ctypes.c_void_p(out.data_ptr()), B, H, W, cin, R, clamp,
+        ctypes.c_void_p(stream_ptr())))
+    torch.cuda.synchronize()
+    want = oracle.bicubic_upsample(img, R) + oracle.subpixel_conv(feat, w)
+    if clamp:
+        want = want.clamp(0, 1)
+    err = (out.float().cpu() - want).abs().max().item()
+    assert err < OP_TOL[dt], f"max-abs {err}"

@@ -22,6 +22,7 @@ def test_model_case(name):
     case = GoldenCase(name)
     shapes = oracle.parameter_shapes(case.config)
     assert {k: list(v) for k, v in shapes.items()} == case.meta["shapes"]
+    assert list(shapes) == list(case.meta["shapes"])  # same order as the reference's state_dict()
     assert sum(int(np.prod(s)) if s else 1 for s in shapes.values()) == case.meta["num_params"]
     taps = {}
     with torch.inference_mode():

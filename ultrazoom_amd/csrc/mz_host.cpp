@@ -1,0 +1,853 @@
+// Host runtime of libmewzoom_hip.so: configuration checks, weight registry + packing, workspace
+// planning, the layer schedule of the MewZoom forward pass, and the C ABI (include/mewzoom_hip.h).
+//
+// The schedule follows the reference's MewZoom.forward (src/ultrazoom/model.py:149-164) and its
+// sub-modules; each step cites the reference lines it replaces.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/mewzoom_hip.h"
+#include "mz_kernels.h"
+
+using namespace mz;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(MZ_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+static int ensure_device_ready() {
+    static int state = 0;  // 0 unknown, 1 ok, -1 failed
+    if (state == 1) return MZ_OK;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(MZ_ERR_NO_DEVICE, "no HIP device visible");
+    hipError_t e = init_kernels();
+    if (e != hipSuccess) return fail(MZ_ERR_HIP, "kernel init failed: %s", hipGetErrorString(e));
+    state = 1;
+    return MZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// model description
+// ------------------------------------------------------------------------------------------------
+struct ConvW {
+    // logical (reference) shape
+    int cout = 0, cin = 0, kh = 0, kw = 0;
+    // kernel selection
+    int mode = MODE_CONV3, taps = 9, nt = 1, ntiles = 1, nchunks = 1;
+    int out_map = OUT_PLAIN, cq = 0, cq_p = 0;
+    int in_map = SRC_PLAIN, c0 = 0, cp0 = 0, c1 = 0;
+    int n_logical_padded = 0;
+    void* packed = nullptr;
+    size_t packed_sz = 0;
+    bool set = false;
+};
+
+static void plan_conv(ConvW& c, int dtype, int mode, int cout, int cin, int kh, int kw, int out_map, int in_map,
+                      int c0, int c1) {
+    const int ck = chunk_channels(dtype);
+    c.cout = cout; c.cin = cin; c.kh = kh; c.kw = kw;
+    c.mode = mode;
+    c.taps = mode == MODE_CONV3 ? 9 : 1;
+    c.out_map = out_map;
+    c.in_map = in_map;
+    if (out_map == OUT_D2S) {
+        c.cq = cout / 4;
+        c.cq_p = pad16(c.cq);
+        c.n_logical_padded = 4 * c.cq_p;
+    } else if (out_map == OUT_FINAL) {
+        c.n_logical_padded = 16;
+    } else {
+        c.n_logical_padded = pad16(cout);
+    }
+    c.nt = choose_nt(c.n_logical_padded);
+    c.ntiles = (c.n_logical_padded + 32 * c.nt - 1) / (32 * c.nt);
+    if (in_map == SRC_PLAIN) {
+        c.c0 = cin; c.cp0 = pad16(cin); c.c1 = 0;
+        c.nchunks = c.cp0 / ck;
+    } else if (in_map == SRC_CONCAT) {
+        c.c0 = c0; c.cp0 = pad16(c0); c.c1 = c1;
+        c.nchunks = (c.cp0 + pad16(c1)) / ck;
+    } else {  // CRUSH
+        c.c0 = cin; c.cp0 = pad16(cin); c.c1 = 0;
+        c.nchunks = 4 * c.cp0 / ck;
+    }
+    c.packed_sz = packed_bytes(c.taps, c.nt, c.ntiles, c.nchunks);
+}
+
+struct BlockW {
+    ConvW conv1, conv2, mix;
+    float alpha = 0.f;
+    bool alpha_set = false;
+};
+
+enum SlotKind { SK_CONV, SK_ALPHA, SK_STEM_W, SK_STEM_B, SK_QA_B };
+struct Slot {
+    std::string name;
+    int kind;
+    ConvW* conv = nullptr;
+    BlockW* block = nullptr;  // for alpha (or skip mixes: alpha stored in skip_alpha)
+    float* alpha = nullptr;
+    bool* flag = nullptr;
+    int64_t shape[4] = {0, 0, 0, 0};
+    int ndim = 0;
+};
+
+struct ProfRec {
+    hipEvent_t a, b;
+    double flops, bytes;
+    int is_conv3;
+};
+
+struct mz_handle {
+    mz_config cfg;
+    int dtype;
+    int ch[4], enc[4], dec[4];
+    int nhead;
+    // weights
+    std::vector<std::unique_ptr<BlockW>> enc_blocks[4], dec_blocks[4], head_blocks;
+    ConvW crush[3], up[3], skipmix[3];
+    float skip_alpha[3] = {0, 0, 0};
+    bool skip_alpha_set[3] = {false, false, false};
+    std::vector<std::unique_ptr<ConvW>> head_up;
+    ConvW qa_conv;
+    float* stem_w4 = nullptr;  // [cp0][4]
+    float* qa_bias = nullptr;  // [F]
+    bool stem_w_set = false, stem_b_set = false, qa_b_set = false;
+    void* zero_page = nullptr;
+    std::vector<Slot> slots;
+    std::unordered_map<std::string, int> slot_index;
+    bool device_ready = false;
+    int use_glds = 1;
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> recs;
+    size_t recs_used = 0;
+};
+
+static void add_slot(mz_handle* h, const std::string& name, int kind, std::initializer_list<int64_t> shape) {
+    Slot s;
+    s.name = name;
+    s.kind = kind;
+    s.ndim = (int)shape.size();
+    int i = 0;
+    for (auto d : shape) s.shape[i++] = d;
+    h->slot_index[name] = (int)h->slots.size();
+    h->slots.push_back(s);
+}
+
+static void add_block(mz_handle* h, BlockW* b, const std::string& prefix, int c) {
+    const int hr = h->cfg.hidden_ratio;
+    plan_conv(b->conv1, h->dtype, MODE_CONV3, hr * c, c, 3, 3, OUT_PLAIN, SRC_PLAIN, 0, 0);      // model.py:742-744
+    plan_conv(b->conv2, h->dtype, MODE_CONV3, c, hr * c, 3, 3, OUT_PLAIN, SRC_PLAIN, 0, 0);      // model.py:746-748
+    plan_conv(b->mix, h->dtype, MODE_GEMM1, c, 2 * c, 1, 1, OUT_PLAIN, SRC_CONCAT, c, c);        // model.py:805
+    add_slot(h, prefix + ".convnet.conv1.weight", SK_CONV, {hr * c, c, 3, 3});
+    h->slots.back().conv = &b->conv1;
+    add_slot(h, prefix + ".convnet.conv2.weight", SK_CONV, {c, hr * c, 3, 3});
+    h->slots.back().conv = &b->conv2;
+    add_slot(h, prefix + ".skip.alpha", SK_ALPHA, {});  // a module's own parameters precede its children's
+    h->slots.back().alpha = &b->alpha;
+    h->slots.back().flag = &b->alpha_set;
+    add_slot(h, prefix + ".skip.conv.weight", SK_CONV, {c, 2 * c, 1, 1});
+    h->slots.back().conv = &b->mix;
+}
+
+static int validate(const mz_config& c) {
+    // Same rejected values as the reference constructor (AssertionError there).
+    if (!(c.upscale_ratio == 2 || c.upscale_ratio == 4 || c.upscale_ratio == 8))  // model.py:67-69
+        return fail(MZ_ERR_INVALID_ARGUMENT, "Upscale ratio must be one of {2, 4, 8}, but got %d.", c.upscale_ratio);
+    if (c.primary_channels <= 3)  // model.py:218-222
+        return fail(MZ_ERR_INVALID_ARGUMENT, "Output channels must be greater than input channels.");
+    const int ch[4] = {c.primary_channels, c.secondary_channels, c.tertiary_channels, c.quaternary_channels};
+    const int ly[4] = {c.primary_layers, c.secondary_layers, c.tertiary_layers, c.quaternary_layers};
+    const char* nm[4] = {"primary", "secondary", "tertiary", "quaternary"};
+    for (int i = 0; i < 4; ++i) {
+        if (ly[i] <= 1)  // model.py:265-275
+            return fail(MZ_ERR_INVALID_ARGUMENT, "Number of %s layers must be greater than 1.", nm[i]);
+        if (ch[i] <= 0) return fail(MZ_ERR_INVALID_ARGUMENT, "Number of channels must be greater than 0.");  // :737
+    }
+    if (!(c.hidden_ratio == 1 || c.hidden_ratio == 2 || c.hidden_ratio == 4))  // model.py:738
+        return fail(MZ_ERR_INVALID_ARGUMENT, "Hidden ratio must be either 1, 2, or 4.");
+    if (c.num_deg_features <= 0)  // model.py:356-358 (intent)
+        return fail(MZ_ERR_INVALID_ARGUMENT, "Number of quality assessor features must be greater than 0.");
+    return MZ_OK;
+}
+
+extern "C" int mz_create(const mz_config* cfg, int dtype, mz_handle** out) {
+    if (!cfg || !out) return fail(MZ_ERR_INVALID_ARGUMENT, "null argument");
+    if (dtype != MZ_F32 && dtype != MZ_BF16 && dtype != MZ_F16) return fail(MZ_ERR_INVALID_ARGUMENT, "bad dtype %d", dtype);
+    int rc = validate(*cfg);
+    if (rc) return rc;
+    auto* h = new mz_handle();
+    h->cfg = *cfg;
+    h->dtype = dtype;
+    const int ch[4] = {cfg->primary_channels, cfg->secondary_channels, cfg->tertiary_channels, cfg->quaternary_channels};
+    const int ly[4] = {cfg->primary_layers, cfg->secondary_layers, cfg->tertiary_layers, cfg->quaternary_layers};
+    for (int i = 0; i < 4; ++i) {
+        h->ch[i] = ch[i];
+        h->enc[i] = (ly[i] + 1) / 2;  // ceil, model.py:277-288
+        h->dec[i] = ly[i] / 2;        // floor, model.py:290-300
+    }
+    h->nhead = cfg->upscale_ratio == 2 ? 1 : (cfg->upscale_ratio == 4 ? 2 : 3);  // model.py:945
+    if (const char* e = getenv("MZ_USE_GLDS")) h->use_glds = atoi(e) != 0;
+
+    // Registry in the reference's state_dict order.
+    h->slots.reserve(1024);
+    add_slot(h, "stem.conv.weight", SK_STEM_W, {ch[0], 3, 1, 1});
+    add_slot(h, "stem.conv.bias", SK_STEM_B, {ch[0]});
+    for (int s = 0; s < 4; ++s) {
+        for (int i = 0; i < h->enc[s]; ++i) {
+            h->enc_blocks[s].emplace_back(new BlockW());
+            add_block(h, h->enc_blocks[s].back().get(), "unet.encoder.stage" + std::to_string(s + 1) + "." + std::to_string(i), ch[s]);
+        }
+    }
+    for (int s = 0; s < 3; ++s) {  // model.py:388-390, 857-863
+        plan_conv(h->crush[s], dtype, MODE_GEMM1, ch[s + 1], ch[s], 2, 2, OUT_PLAIN, SRC_CRUSH, 0, 0);
+        add_slot(h, "unet.encoder.downsample" + std::to_string(s + 1) + ".conv.weight", SK_CONV, {ch[s + 1], ch[s], 2, 2});
+        h->slots.back().conv = &h->crush[s];
+    }
+    plan_conv(h->qa_conv, dtype, MODE_CONV3, cfg->num_deg_features, ch[3], 3, 3, OUT_PLAIN, SRC_PLAIN, 0, 0);  // :1010
+    add_slot(h, "unet.encoder.qa_head.conv.weight", SK_CONV, {cfg->num_deg_features, ch[3], 3, 3});
+    h->slots.back().conv = &h->qa_conv;
+    add_slot(h, "unet.encoder.qa_head.conv.bias", SK_QA_B, {cfg->num_deg_features});
+    for (int d = 0; d < 4; ++d) {  // decoder stage1 = coarsest level (model.py:290-300)
+        const int lvl = 3 - d;
+        for (int i = 0; i < h->dec[lvl]; ++i) {
+            h->dec_blocks[d].emplace_back(new BlockW());
+            add_block(h, h->dec_blocks[d].back().get(), "unet.decoder.stage" + std::to_string(d + 1) + "." + std::to_string(i), ch[lvl]);
+        }
+    }
+    for (int d = 0; d < 3; ++d) {
+        const int cin = ch[3 - d], cout = ch[2 - d];
+        plan_conv(h->up[d], dtype, MODE_CONV3, 4 * cout, cin, 3, 3, OUT_D2S, SRC_PLAIN, 0, 0);  // model.py:569-571, 900-911
+        add_slot(h, "unet.decoder.upsample" + std::to_string(d + 1) + ".conv.weight", SK_CONV, {4 * cout, cin, 3, 3});
+        h->slots.back().conv = &h->up[d];
+    }
+    for (int d = 0; d < 3; ++d) {
+        const int cout = ch[2 - d];
+        plan_conv(h->skipmix[d], dtype, MODE_GEMM1, cout, 2 * cout, 1, 1, OUT_PLAIN, SRC_CONCAT, cout, cout);  // model.py:573-575
+        add_slot(h, "unet.decoder.skip" + std::to_string(d + 1) + ".alpha", SK_ALPHA, {});
+        h->slots.back().alpha = &h->skip_alpha[d];
+        h->slots.back().flag = &h->skip_alpha_set[d];
+        add_slot(h, "unet.decoder.skip" + std::to_string(d + 1) + ".conv.weight", SK_CONV, {cout, 2 * cout, 1, 1});
+        h->slots.back().conv = &h->skipmix[d];
+    }
+    for (int i = 0; i < h->nhead; ++i) {  // model.py:945-954, 981-983
+        h->head_blocks.emplace_back(new BlockW());
+        add_block(h, h->head_blocks.back().get(), "head.layers." + std::to_string(i) + ".refiner", ch[0]);
+        const bool last = i == h->nhead - 1;
+        const int cout = last ? 3 : ch[0];
+        h->head_up.emplace_back(new ConvW());
+        plan_conv(*h->head_up.back(), dtype, MODE_CONV3, 4 * cout, ch[0], 3, 3, last ? OUT_FINAL : OUT_D2S, SRC_PLAIN, 0, 0);
+        add_slot(h, "head.layers." + std::to_string(i) + ".upscale.conv.weight", SK_CONV, {4 * cout, ch[0], 3, 3});
+        h->slots.back().conv = h->head_up.back().get();
+    }
+    *out = h;
+    return MZ_OK;
+}
+
+static void free_conv(ConvW& c) {
+    if (c.packed) (void)hipFree(c.packed);
+    c.packed = nullptr;
+}
+
+extern "C" int mz_destroy(mz_handle* h) {
+    if (!h) return MZ_OK;
+    for (auto& s : h->slots)
+        if (s.kind == SK_CONV && s.conv) free_conv(*s.conv);
+    if (h->stem_w4) (void)hipFree(h->stem_w4);
+    if (h->qa_bias) (void)hipFree(h->qa_bias);
+    if (h->zero_page) (void)hipFree(h->zero_page);
+    for (auto& r : h->recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    delete h;
+    return MZ_OK;
+}
+
+extern "C" int mz_num_weights(const mz_handle* h) { return h ? (int)h->slots.size() : 0; }
+
+extern "C" int mz_weight_info(const mz_handle* h, int index, const char** name, int64_t shape[4]) {
+    if (!h || index < 0 || index >= (int)h->slots.size()) return fail(MZ_ERR_INVALID_ARGUMENT, "bad weight index");
+    const Slot& s = h->slots[index];
+    if (name) *name = s.name.c_str();
+    if (shape)
+        for (int i = 0; i < 4; ++i) shape[i] = s.shape[i];
+    return s.ndim;
+}
+
+static int prepare_device(mz_handle* h) {
+    if (h->device_ready) return MZ_OK;
+    int rc = ensure_device_ready();
+    if (rc) return rc;
+    HIPCHK(hipMalloc(&h->zero_page, 4096));
+    HIPCHK(hipMemset(h->zero_page, 0, 4096));
+    const int cp0 = pad16(h->ch[0]);
+    HIPCHK(hipMalloc((void**)&h->stem_w4, sizeof(float) * 4 * cp0));
+    HIPCHK(hipMemset(h->stem_w4, 0, sizeof(float) * 4 * cp0));
+    HIPCHK(hipMalloc((void**)&h->qa_bias, sizeof(float) * std::max(1, h->cfg.num_deg_features)));
+    h->device_ready = true;
+    return MZ_OK;
+}
+
+static int pack_conv(ConvW& c, int dtype, const float* w_dev, hipStream_t s) {
+    if (!c.packed) HIPCHK(hipMalloc(&c.packed, c.packed_sz));
+    PackArgs p;
+    p.w = w_dev; p.dst = c.packed; p.dtype = dtype;
+    p.cout = c.cout; p.cin = c.cin; p.kh = c.kh; p.kw = c.kw;
+    p.taps = c.taps; p.nt = c.nt; p.ntiles = c.ntiles; p.nchunks = c.nchunks;
+    p.out_map = c.out_map; p.cq = c.cq; p.cq_p = c.cq_p;
+    p.in_map = c.in_map; p.c0 = c.c0; p.cp0 = c.cp0; p.c1 = c.c1;
+    HIPCHK(launch_pack(p, s));
+    c.set = true;
+    return MZ_OK;
+}
+
+extern "C" int mz_set_weight(mz_handle* h, const char* name, const float* dev_f32, const int64_t* shape, int ndim,
+                             void* hip_stream) {
+    if (!h || !name || !dev_f32) return fail(MZ_ERR_INVALID_ARGUMENT, "null argument");
+    auto it = h->slot_index.find(name);
+    if (it == h->slot_index.end()) return fail(MZ_ERR_UNKNOWN_WEIGHT, "unknown parameter '%s'", name);
+    Slot& s = h->slots[it->second];
+    if (ndim != s.ndim) return fail(MZ_ERR_SHAPE_MISMATCH, "'%s': expected %d dims, got %d", name, s.ndim, ndim);
+    for (int i = 0; i < ndim; ++i)
+        if (shape[i] != s.shape[i])
+            return fail(MZ_ERR_SHAPE_MISMATCH, "'%s': dim %d is %lld, expected %lld", name, i, (long long)shape[i], (long long)s.shape[i]);
+    int rc = prepare_device(h);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    switch (s.kind) {
+        case SK_CONV: return pack_conv(*s.conv, h->dtype, dev_f32, st);
+        case SK_ALPHA: {
+            // sigmoid(alpha) is folded on the host (model.py:833); one 4-byte read at load time.
+            float v = 0.f;
+            HIPCHK(hipMemcpyAsync(&v, dev_f32, sizeof(float), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            *s.alpha = v;
+            *s.flag = true;
+            return MZ_OK;
+        }
+        case SK_STEM_W:
+            HIPCHK(launch_pack_stem(dev_f32, nullptr, h->stem_w4, h->ch[0], pad16(h->ch[0]), st));
+            h->stem_w_set = true;
+            return MZ_OK;
+        case SK_STEM_B:
+            HIPCHK(launch_pack_stem(nullptr, dev_f32, h->stem_w4, h->ch[0], pad16(h->ch[0]), st));
+            h->stem_b_set = true;
+            return MZ_OK;
+        case SK_QA_B:
+            HIPCHK(hipMemcpyAsync(h->qa_bias, dev_f32, sizeof(float) * h->cfg.num_deg_features, hipMemcpyDeviceToDevice, st));
+            h->qa_b_set = true;
+            return MZ_OK;
+    }
+    return fail(MZ_ERR_INVALID_ARGUMENT, "bad slot");
+}
+
+extern "C" int mz_weights_complete(const mz_handle* h) {
+    if (!h) return fail(MZ_ERR_INVALID_ARGUMENT, "null handle");
+    for (const Slot& s : h->slots) {
+        bool ok = true;
+        switch (s.kind) {
+            case SK_CONV: ok = s.conv->set; break;
+            case SK_ALPHA: ok = *s.flag; break;
+            case SK_STEM_W: ok = h->stem_w_set; break;
+            case SK_STEM_B: ok = h->stem_b_set; break;
+            case SK_QA_B: ok = h->qa_b_set; break;
+        }
+        if (!ok) return fail(MZ_ERR_MISSING_WEIGHTS, "parameter '%s' has not been set", s.name.c_str());
+    }
+    return MZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace plan
+// ------------------------------------------------------------------------------------------------
+struct Plan {
+    int nb;                // images per micro-batch
+    int hs[4], ws[4];      // level sizes
+    size_t R[4][3], HID[4], Z[4], U[3];
+    size_t HR[3][2], HHID[3], HZ[3];  // head levels 1..nhead-1 (index j-1... stored at j)
+    size_t QA;
+    size_t total;
+};
+
+static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static void make_plan(const mz_handle* h, int nb, int H, int W, Plan& p) {
+    const size_t sz = dtype_size(h->dtype);
+    const int hr = h->cfg.hidden_ratio;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += align_up(bytes);
+        return o;
+    };
+    p.nb = nb;
+    p.hs[0] = H; p.ws[0] = W;
+    for (int i = 1; i < 4; ++i) { p.hs[i] = p.hs[i - 1] / 2; p.ws[i] = p.ws[i - 1] / 2; }
+    for (int l = 0; l < 4; ++l) {
+        const size_t px = (size_t)nb * p.hs[l] * p.ws[l];
+        const size_t c = px * pad16(h->ch[l]) * sz;
+        for (int k = 0; k < 3; ++k) p.R[l][k] = take(c);
+        p.HID[l] = take(px * pad16(hr * h->ch[l]) * sz);
+        p.Z[l] = take(c);
+        if (l < 3) p.U[l] = take(c);
+    }
+    for (int j = 1; j < h->nhead; ++j) {
+        const size_t px = (size_t)nb * (H << j) * (W << j);
+        const size_t c = px * pad16(h->ch[0]) * sz;
+        p.HR[j][0] = take(c);
+        p.HR[j][1] = take(c);
+        p.HHID[j] = take(px * pad16(hr * h->ch[0]) * sz);
+        p.HZ[j] = take(c);
+    }
+    p.QA = take((size_t)nb * p.hs[3] * p.ws[3] * pad16(h->cfg.num_deg_features) * sz);
+    p.total = off;
+}
+
+static int default_micro_batch(const mz_handle* h, int B, int H, int W, int requested) {
+    if (requested > 0) return std::min(B, requested);
+    // keep a micro-batch's workspace around <= 48 GiB by default (288 GB of HBM per GPU)
+    Plan p;
+    make_plan(h, 1, H, W, p);
+    const size_t budget = (size_t)48 << 30;
+    int nb = (int)std::max<size_t>(1, budget / std::max<size_t>(1, p.total));
+    return std::max(1, std::min(B, nb));
+}
+
+extern "C" int mz_workspace_bytes(const mz_handle* h, int B, int H, int W, int max_images_in_flight, size_t* bytes) {
+    if (!h || !bytes) return fail(MZ_ERR_INVALID_ARGUMENT, "null argument");
+    if (B <= 0 || H < 8 || W < 8) return fail(MZ_ERR_INVALID_ARGUMENT, "need B >= 1 and H, W >= 8 (got %d, %d, %d)", B, H, W);
+    Plan p;
+    make_plan(h, default_micro_batch(h, B, H, W, max_images_in_flight), H, W, p);
+    *bytes = p.total;
+    return MZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+struct Runner {
+    mz_handle* h;
+    hipStream_t s;
+    int dtype;
+    int rc = MZ_OK;
+
+    void prof_begin(ProfRec*& r, double flops, double bytes, int is_conv3) {
+        r = nullptr;
+        if (!h || !h->prof) return;
+        if (h->recs_used == h->recs.size()) {
+            ProfRec n;
+            if (hipEventCreate(&n.a) != hipSuccess || hipEventCreate(&n.b) != hipSuccess) return;
+            h->recs.push_back(n);
+        }
+        r = &h->recs[h->recs_used++];
+        r->flops = flops; r->bytes = bytes; r->is_conv3 = is_conv3;
+        (void)hipEventRecord(r->a, s);
+    }
+    void prof_end(ProfRec* r) {
+        if (r) (void)hipEventRecord(r->b, s);
+    }
+
+    int check(hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == MZ_OK) rc = fail(MZ_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+        return rc;
+    }
+
+    void base_args(ConvArgs& a, const ConvW& c) {
+        memset(&a, 0, sizeof(a));
+        a.wpk = c.packed;
+        a.zero = h ? h->zero_page : nullptr;
+        a.nchunks = c.nchunks;
+        a.ntiles = c.ntiles;
+        a.use_glds = h ? h->use_glds : 1;
+    }
+
+    void pick_order(ConvArgs& a, const ConvW& c, double act_bytes) {
+        // Walk N tiles fastest when re-streaming the weights per pixel tile is cheaper than
+        // re-reading the activations per N tile (both from L2 / Infinity Cache).
+        const double w_traffic = (double)a.mtiles * (double)c.packed_sz;
+        const double a_traffic = (double)a.ntiles * act_bytes;
+        a.n_fast = (a.ntiles == 1 || w_traffic <= a_traffic) ? 1 : 0;
+    }
+
+    // conv3x3, pad 1 (model.py:742-748, 900-909, 1010). epi: STORE / D2S / FINAL
+    void conv3(const ConvW& c, const void* in, void* out, int B, int H, int W, int epi, int silu, int Hout, int Wout,
+               const void* img = nullptr, int R = 0, int clamp = 0, const void* zero_override = nullptr) {
+        if (rc) return;
+        ConvArgs a;
+        base_args(a, c);
+        if (zero_override) a.zero = zero_override;
+        a.in0 = in; a.out = out;
+        a.B = B; a.H = H; a.W = W; a.Ho = H; a.Wo = W;
+        a.cp0 = c.cp0;
+        a.src = SRC_PLAIN;
+        a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 7) / 8;
+        a.mtiles = B * a.tiles_x * a.tiles_y;
+        a.epi = epi; a.silu = silu;
+        a.cp_out = epi == EPI_D2S ? c.cq_p : pad16(c.cout);
+        a.Hout = Hout; a.Wout = Wout;
+        a.img = img; a.R = R; a.clamp = clamp;
+        if (epi == EPI_FINAL) { a.Hi = Hout / R; a.Wi = Wout / R; }
+        const double sz = dtype_size(dtype);
+        const double px = (double)B * H * W;
+        pick_order(a, c, px * c.cp0 * sz);
+        ProfRec* r;
+        prof_begin(r, 2.0 * px * 9.0 * c.cin * c.cout, px * (c.cin + c.cout) * sz + 9.0 * c.cin * c.cout * sz, 1);
+        check(launch_conv(dtype, MODE_CONV3, c.nt, a, s), "conv3x3 launch");
+        prof_end(r);
+    }
+
+    // AdaptiveResidualMix (model.py:826-839): out = x + sigmoid(alpha)*sigmoid(W[x;z])*(z - x)
+    void mix(const ConvW& c, float alpha, const void* x, const void* z, void* out, long long npix,
+             const void* zero_override = nullptr) {
+        if (rc) return;
+        ConvArgs a;
+        base_args(a, c);
+        if (zero_override) a.zero = zero_override;
+        a.in0 = x; a.in1 = z; a.out = out;
+        a.B = 1; a.H = 1; a.W = 1; a.Ho = 1; a.Wo = (int)npix;
+        a.B = 1; a.Ho = 1;
+        // linear pixel grid: B*Ho*Wo = npix
+        a.cp0 = c.cp0; a.cp1 = pad16(c.c1);
+        a.nchunks0 = c.cp0 / chunk_channels(dtype);
+        a.src = SRC_CONCAT;
+        a.mtiles = (int)((npix + 255) / 256);
+        a.epi = EPI_MIX;
+        a.cp_out = pad16(c.cout);
+        a.mix_scale = 1.0f / (1.0f + std::exp(-alpha));
+        const double sz = dtype_size(dtype);
+        pick_order(a, c, (double)npix * (a.cp0 + a.cp1) * sz);
+        ProfRec* r;
+        prof_begin(r, 2.0 * (double)npix * c.cin * c.cout, (double)npix * 3.0 * c.cout * sz, 0);
+        check(launch_conv(dtype, MODE_GEMM1, c.nt, a, s), "mix launch");
+        prof_end(r);
+    }
+
+    // PixelCrush (model.py:857-863, 881-882): conv 2x2 stride 2, floors odd sizes
+    void crush(const ConvW& c, const void* in, void* out, int B, int H, int W, const void* zero_override = nullptr) {
+        if (rc) return;
+        ConvArgs a;
+        base_args(a, c);
+        if (zero_override) a.zero = zero_override;
+        a.in0 = in; a.out = out;
+        a.B = B; a.H = H; a.W = W; a.Ho = H / 2; a.Wo = W / 2;
+        a.cp0 = c.cp0;
+        a.nchunks0 = c.cp0 / chunk_channels(dtype);
+        a.src = SRC_CRUSH;
+        const long long npix = (long long)B * a.Ho * a.Wo;
+        a.mtiles = (int)((npix + 255) / 256);
+        a.epi = EPI_STORE;
+        a.cp_out = pad16(c.cout);
+        const double sz = dtype_size(dtype);
+        pick_order(a, c, (double)B * H * W * c.cp0 * sz);
+        ProfRec* r;
+        prof_begin(r, 2.0 * (double)npix * 4.0 * c.cin * c.cout, ((double)B * H * W * c.cin + (double)npix * c.cout) * sz, 0);
+        check(launch_conv(dtype, MODE_GEMM1, c.nt, a, s), "crush launch");
+        prof_end(r);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+static int forward_micro(mz_handle* h, const char* x, char* out_sr, float* out_qa, int nb, int H, int W, int clamp,
+                         char* ws, hipStream_t s) {
+    Plan p;
+    make_plan(h, nb, H, W, p);
+    Runner run{h, s, h->dtype};
+    const int r = h->cfg.upscale_ratio;
+
+    auto block = [&](const BlockW& b, const void* xin, void* hid, void* z, void* yout, int hh, int ww) {
+        // EncoderBlock / DecoderBlock (model.py:507-511): conv1 -> SiLU -> conv2 -> adaptive mix with the input
+        run.conv3(b.conv1, xin, hid, nb, hh, ww, EPI_STORE, 1, 0, 0);
+        run.conv3(b.conv2, hid, z, nb, hh, ww, EPI_STORE, 0, 0, 0);
+        run.mix(b.mix, b.alpha, xin, z, yout, (long long)nb * hh * ww);
+    };
+
+    // stem (model.py:158): NCHW image -> NHWC features
+    char* cur = ws + p.R[0][0];
+    if (hipError_t e = launch_stem(h->dtype, x, h->stem_w4, cur, nb, H, W, pad16(h->ch[0]), s); e != hipSuccess)
+        return fail(MZ_ERR_HIP, "stem launch: %s", hipGetErrorString(e));
+
+    // encoder (model.py:461-484)
+    char* feat[4];
+    int feat_slot[4];
+    for (int l = 0; l < 4; ++l) {
+        int slot = 0;
+        if (l > 0) {
+            cur = ws + p.R[l][0];
+            run.crush(h->crush[l - 1], feat[l - 1], cur, nb, p.hs[l - 1], p.ws[l - 1]);
+        }
+        for (auto& b : h->enc_blocks[l]) {
+            char* nxt = ws + p.R[l][slot ^ 1];
+            block(*b, cur, ws + p.HID[l], ws + p.Z[l], nxt, p.hs[l], p.ws[l]);
+            cur = nxt;
+            slot ^= 1;
+        }
+        feat[l] = cur;
+        feat_slot[l] = slot;
+    }
+
+    // quality head (model.py:482, 1026-1032); upscale() discards it (model.py:175)
+    if (out_qa) {
+        const int F = h->cfg.num_deg_features;
+        run.conv3(h->qa_conv, feat[3], ws + p.QA, nb, p.hs[3], p.ws[3], EPI_STORE, 0, 0, 0);
+        if (run.rc) return run.rc;
+        if (hipError_t e = launch_qa_reduce(h->dtype, ws + p.QA, h->qa_bias, out_qa, nb, p.hs[3] * p.ws[3], pad16(F), F, s);
+            e != hipSuccess)
+            return fail(MZ_ERR_HIP, "qa reduce launch: %s", hipGetErrorString(e));
+    }
+
+    // decoder (model.py:691-724)
+    cur = feat[3];
+    int slot = feat_slot[3];
+    for (int d = 0; d < 4; ++d) {
+        const int l = 3 - d;
+        if (d > 0) {
+            // SubpixelConv2d (model.py:926-930) + crop_feature_maps zero pad (model.py:650-689) + skip mix (:701)
+            const ConvW& up = h->up[d - 1];
+            char* u = ws + p.U[l];
+            run.conv3(up, cur, u, nb, p.hs[l + 1], p.ws[l + 1], EPI_D2S, 0, p.hs[l], p.ws[l]);
+            if (run.rc) return run.rc;
+            if (hipError_t e = launch_zero_border(h->dtype, u, nb, p.hs[l], p.ws[l], up.cq_p, 2 * p.hs[l + 1], 2 * p.ws[l + 1], s);
+                e != hipSuccess)
+                return fail(MZ_ERR_HIP, "zero border launch: %s", hipGetErrorString(e));
+            // pick a level-l buffer that is not the saved encoder feature
+            slot = (feat_slot[l] + 1) % 3;
+            char* dst = ws + p.R[l][slot];
+            run.mix(h->skipmix[d - 1], h->skip_alpha[d - 1], feat[l], u, dst, (long long)nb * p.hs[l] * p.ws[l]);
+            cur = dst;
+        }
+        for (auto& b : h->dec_blocks[d]) {
+            int nslot = (slot + 1) % 3;
+            if (d > 0 && nslot == feat_slot[l]) nslot = (nslot + 1) % 3;  // (the encoder feature is dead after the skip mix, but keep it simple)
+            char* nxt = ws + p.R[l][nslot];
+            block(*b, cur, ws + p.HID[l], ws + p.Z[l], nxt, p.hs[l], p.ws[l]);
+            cur = nxt;
+            slot = nslot;
+        }
+    }
+
+    // head (model.py:968-972, 997-1001) + bicubic skip + residual add + clamp (model.py:156,162,177)
+    int hh = H, ww = W;
+    for (int i = 0; i < h->nhead; ++i) {
+        char *hid, *z, *y;
+        if (i == 0) {
+            hid = ws + p.HID[0]; z = ws + p.Z[0];
+            int nslot = (slot + 1) % 3;
+            y = ws + p.R[0][nslot];
+        } else {
+            hid = ws + p.HHID[i]; z = ws + p.HZ[i]; y = ws + p.HR[i][1];
+        }
+        block(*h->head_blocks[i], cur, hid, z, y, hh, ww);
+        const bool last = i == h->nhead - 1;
+        if (last) {
+            run.conv3(*h->head_up[i], y, out_sr, nb, hh, ww, EPI_FINAL, 0, 2 * hh, 2 * ww, x, r, clamp);
+        } else {
+            char* nxt = ws + p.HR[i + 1][0];
+            run.conv3(*h->head_up[i], y, nxt, nb, hh, ww, EPI_D2S, 0, 2 * hh, 2 * ww);
+            cur = nxt;
+            hh *= 2; ww *= 2;
+        }
+    }
+    return run.rc;
+}
+
+extern "C" int mz_forward(mz_handle* h, const void* x, void* out_sr, float* out_qa, int B, int H, int W, int clamp,
+                          void* workspace, size_t workspace_bytes, int max_images_in_flight, void* hip_stream) {
+    if (!h || !x || !out_sr || !workspace) return fail(MZ_ERR_INVALID_ARGUMENT, "null argument");
+    if (B <= 0 || H < 8 || W < 8) return fail(MZ_ERR_INVALID_ARGUMENT, "need B >= 1 and H, W >= 8 (got %d, %d, %d)", B, H, W);
+    int rc = mz_weights_complete(h);
+    if (rc) return rc;
+    const int nbmax = default_micro_batch(h, B, H, W, max_images_in_flight);
+    Plan p;
+    make_plan(h, nbmax, H, W, p);
+    if (workspace_bytes < p.total)
+        return fail(MZ_ERR_WORKSPACE_TOO_SMALL, "workspace too small: %zu bytes given, %zu needed", workspace_bytes, p.total);
+    const size_t sz = dtype_size(h->dtype);
+    const int r = h->cfg.upscale_ratio;
+    const size_t in_img = (size_t)3 * H * W * sz;
+    const size_t out_img = (size_t)3 * H * r * W * r * sz;
+    for (int b0 = 0; b0 < B; b0 += nbmax) {
+        const int nb = std::min(nbmax, B - b0);
+        rc = forward_micro(h, (const char*)x + b0 * in_img, (char*)out_sr + b0 * out_img,
+                           out_qa ? out_qa + (size_t)b0 * h->cfg.num_deg_features : nullptr, nb, H, W, clamp,
+                           (char*)workspace, (hipStream_t)hip_stream);
+        if (rc) return rc;
+    }
+    return MZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// operator-level entry points (tests)
+// ------------------------------------------------------------------------------------------------
+extern "C" int mz_padded_channels(int c) { return pad16(c); }
+
+struct TempBuf {
+    void* p = nullptr;
+    ~TempBuf() {
+        if (p) (void)hipFree(p);
+    }
+};
+
+extern "C" int mz_op_conv(int dtype, int kind, const void* in0, const void* in1, const float* w_dev_f32, float alpha,
+                          void* out, int B, int H, int W, int cin, int cout, int Hout, int Wout, int silu,
+                          void* hip_stream) {
+    int rc = ensure_device_ready();
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)hip_stream;
+    ConvW c;
+    switch (kind) {
+        case 0: plan_conv(c, dtype, MODE_CONV3, cout, cin, 3, 3, OUT_PLAIN, SRC_PLAIN, 0, 0); break;
+        case 1: plan_conv(c, dtype, MODE_CONV3, cout, cin, 3, 3, OUT_D2S, SRC_PLAIN, 0, 0); break;
+        case 2: plan_conv(c, dtype, MODE_GEMM1, cout, cin, 2, 2, OUT_PLAIN, SRC_CRUSH, 0, 0); break;
+        case 3: plan_conv(c, dtype, MODE_GEMM1, cout, 2 * cout, 1, 1, OUT_PLAIN, SRC_CONCAT, cout, cout); break;
+        default: return fail(MZ_ERR_INVALID_ARGUMENT, "bad op kind %d", kind);
+    }
+    TempBuf zero, packed;
+    HIPCHK(hipMalloc(&zero.p, 4096));
+    HIPCHK(hipMemsetAsync(zero.p, 0, 4096, s));
+    rc = pack_conv(c, dtype, w_dev_f32, s);
+    packed.p = c.packed;
+    if (rc) return rc;
+    // a throw-away handle carries the zero page / staging choice for Runner
+    mz_handle fake;
+    fake.zero_page = zero.p;
+    fake.use_glds = 1;
+    if (const char* e = getenv("MZ_USE_GLDS")) fake.use_glds = atoi(e) != 0;
+    Runner run{&fake, s, dtype};
+    switch (kind) {
+        case 0: run.conv3(c, in0, out, B, H, W, EPI_STORE, silu, 0, 0); break;
+        case 1:
+            run.conv3(c, in0, out, B, H, W, EPI_D2S, 0, Hout, Wout);
+            if (!run.rc) {
+                hipError_t e = launch_zero_border(dtype, out, B, Hout, Wout, c.cq_p, 2 * H, 2 * W, s);
+                if (e != hipSuccess) run.rc = fail(MZ_ERR_HIP, "zero border: %s", hipGetErrorString(e));
+            }
+            break;
+        case 2: run.crush(c, in0, out, B, H, W); break;
+        case 3: run.mix(c, alpha, in0, in1, out, (long long)B * H * W); break;
+    }
+    fake.zero_page = nullptr;
+    HIPCHK(hipStreamSynchronize(s));
+    return run.rc;
+}
+
+extern "C" int mz_op_stem(int dtype, const void* x, const float* w_dev_f32, const float* b_dev_f32, void* out, int B,
+                          int H, int W, int cout, void* hip_stream) {
+    int rc = ensure_device_ready();
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)hip_stream;
+    const int cp = pad16(cout);
+    TempBuf w4;
+    HIPCHK(hipMalloc(&w4.p, sizeof(float) * 4 * cp));
+    HIPCHK(hipMemsetAsync(w4.p, 0, sizeof(float) * 4 * cp, s));
+    HIPCHK(launch_pack_stem(w_dev_f32, b_dev_f32, (float*)w4.p, cout, cp, s));
+    HIPCHK(launch_stem(dtype, x, (const float*)w4.p, out, B, H, W, cp, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return MZ_OK;
+}
+
+extern "C" int mz_op_final(int dtype, const void* feat, const void* img, const float* w_dev_f32, void* out, int B, int H,
+                           int W, int cin, int R, int clamp, void* hip_stream) {
+    int rc = ensure_device_ready();
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)hip_stream;
+    ConvW c;
+    plan_conv(c, dtype, MODE_CONV3, 12, cin, 3, 3, OUT_FINAL, SRC_PLAIN, 0, 0);
+    TempBuf zero, packed;
+    HIPCHK(hipMalloc(&zero.p, 4096));
+    HIPCHK(hipMemsetAsync(zero.p, 0, 4096, s));
+    rc = pack_conv(c, dtype, w_dev_f32, s);
+    packed.p = c.packed;
+    if (rc) return rc;
+    mz_handle fake;
+    fake.zero_page = zero.p;
+    fake.use_glds = 1;
+    if (const char* e = getenv("MZ_USE_GLDS")) fake.use_glds = atoi(e) != 0;
+    Runner run{&fake, s, dtype};
+    run.conv3(c, feat, out, B, H, W, EPI_FINAL, 0, 2 * H, 2 * W, img, R, clamp);
+    fake.zero_page = nullptr;
+    HIPCHK(hipStreamSynchronize(s));
+    return run.rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// introspection
+// ------------------------------------------------------------------------------------------------
+extern "C" const char* mz_last_error(void) { return g_err; }
+extern "C" const char* mz_version(void) { return "mewzoom_hip 0.1 (gfx950)"; }
+
+extern "C" double mz_flops_per_image(const mz_handle* h, int H, int W) {
+    if (!h) return 0.0;
+    const int hr = h->cfg.hidden_ratio;
+    int hs[4] = {H, 0, 0, 0}, ws[4] = {W, 0, 0, 0};
+    for (int i = 1; i < 4; ++i) { hs[i] = hs[i - 1] / 2; ws[i] = ws[i - 1] / 2; }
+    double macs = 3.0 * h->ch[0] * H * W;
+    auto blk = [&](double c) { return (18.0 * hr + 2.0) * c * c; };
+    for (int l = 0; l < 4; ++l) macs += (h->enc[l] + h->dec[l]) * blk(h->ch[l]) * hs[l] * ws[l];
+    for (int l = 0; l < 3; ++l) {
+        macs += 4.0 * h->ch[l] * h->ch[l + 1] * hs[l + 1] * ws[l + 1];
+        macs += 9.0 * h->ch[l + 1] * 4.0 * h->ch[l] * hs[l + 1] * ws[l + 1];
+        macs += 2.0 * h->ch[l] * h->ch[l] * hs[l] * ws[l];
+    }
+    macs += 9.0 * h->ch[3] * h->cfg.num_deg_features * hs[3] * ws[3];
+    double hh = H, ww = W;
+    for (int i = 0; i < h->nhead; ++i) {
+        const double cout = (i == h->nhead - 1) ? 3 : h->ch[0];
+        macs += blk(h->ch[0]) * hh * ww + 9.0 * h->ch[0] * 4.0 * cout * hh * ww;
+        hh *= 2; ww *= 2;
+    }
+    return 2.0 * macs;
+}
+
+extern "C" int mz_profile_enable(mz_handle* h, int on) {
+    if (!h) return fail(MZ_ERR_INVALID_ARGUMENT, "null handle");
+    h->prof = on != 0;
+    h->recs_used = 0;
+    return MZ_OK;
+}
+
+extern "C" int mz_profile_read(mz_handle* h, double* conv_ms, double* conv_flops, double* conv_launches, double* other_ms,
+                               double* conv_bytes) {
+    if (!h) return fail(MZ_ERR_INVALID_ARGUMENT, "null handle");
+    double cm = 0, cf = 0, cl = 0, om = 0, cb = 0;
+    for (size_t i = 0; i < h->recs_used; ++i) {
+        ProfRec& r = h->recs[i];
+        HIPCHK(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
+        if (r.is_conv3) { cm += ms; cf += r.flops; cl += 1; cb += r.bytes; }
+        else om += ms;
+    }
+    if (conv_ms) *conv_ms = cm;
+    if (conv_flops) *conv_flops = cf;
+    if (conv_launches) *conv_launches = cl;
+    if (other_ms) *other_ms = om;
+    if (conv_bytes) *conv_bytes = cb;
+    h->recs_used = 0;
+    return MZ_OK;
+}

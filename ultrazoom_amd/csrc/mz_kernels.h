@@ -1,0 +1,98 @@
+// Internal interface between the host runtime (mz_host.cpp) and the gfx950 kernels (mz_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace mz {
+
+enum DType : int { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
+
+inline int dtype_size(int dt) { return dt == DT_F32 ? 4 : 2; }
+// channels per 32-byte K-chunk
+inline int chunk_channels(int dt) { return dt == DT_F32 ? 8 : 16; }
+inline int pad16(int c) { return (c + 15) / 16 * 16; }
+
+// ---- implicit-GEMM convolution ----------------------------------------------------------------
+// A workgroup = 4 waves = 256 output pixels x BN = 32*NT output channels.
+//   MODE_CONV3 : 3x3, pad 1, stride 1; pixel tile = 8 rows x 32 columns of one image.
+//   MODE_GEMM1 : 1x1 over a gathered K axis; pixel tile = 256 consecutive output pixels
+//                (row-major over B*Ho*Wo).  Sources: SRC_CONCAT ([in0 ; in1] along channels, the
+//                AdaptiveResidualMix gate) or SRC_CRUSH (2x2 stride-2 patch of in0 = PixelCrush).
+enum ConvMode : int { MODE_CONV3 = 0, MODE_GEMM1 = 1 };
+enum SrcKind : int { SRC_PLAIN = 0, SRC_CONCAT = 1, SRC_CRUSH = 2 };
+enum Epilogue : int {
+    EPI_STORE = 0,  // NHWC store (optional SiLU)
+    EPI_D2S = 1,    // PixelShuffle(2) store into a [B,Hout,Wout,cq] tensor
+    EPI_MIX = 2,    // out = x + s*sigmoid(acc)*(z - x), x = in0, z = in1
+    EPI_FINAL = 3,  // PixelShuffle(2) + bicubic(img) + add (+clamp) -> NCHW image
+};
+
+struct ConvArgs {
+    const void* in0;
+    const void* in1;
+    const void* wpk;   // packed weights [ntile][kchunk][tap][nt][64 lanes][16 B]
+    void* out;
+    const void* zero;  // >= 16 bytes of zeros in HBM (source for halo / out-of-range pixels)
+    const void* img;   // EPI_FINAL: NCHW low-resolution image
+    int B, H, W;       // input grid
+    int Ho, Wo;        // output pixel grid of the GEMM (== H,W for CONV3; H/2,W/2 for CRUSH)
+    int cp0, cp1;      // padded channels of in0 / in1
+    int nchunks;       // K chunks in total
+    int nchunks0;      // CONCAT: chunks that come from in0; CRUSH: chunks per tap
+    int src;           // SrcKind
+    int ntiles;        // N tiles (of 32*NT channels)
+    int mtiles;        // pixel tiles
+    int tiles_x, tiles_y;  // CONV3: tiles per image
+    int n_fast;        // 1: consecutive workgroups walk the N tiles of one pixel tile
+    int epi;
+    int silu;
+    int cp_out;        // STORE/MIX: padded channels of out; D2S: channels per output pixel (cq_p)
+    int Hout, Wout;    // D2S / FINAL target grid
+    float mix_scale;   // sigmoid(alpha)
+    int R;             // FINAL: total upscale ratio of img -> out
+    int Hi, Wi;        // FINAL: img size
+    int clamp;
+    int use_glds;      // stage through global_load_lds (1) or through registers (0)
+    float bic_w[8][4]; // bicubic phase weights
+    int bic_f[8];      // bicubic phase base offsets (-1 or 0)
+};
+
+size_t conv_lds_bytes(int mode, int nt);
+// picks NT (32*NT output channels per workgroup) for a logical padded N
+int choose_nt(int n_padded);
+hipError_t launch_conv(int dtype, int mode, int nt, const ConvArgs& a, hipStream_t s);
+hipError_t init_kernels();  // raises the dynamic-LDS limits once per process
+
+// ---- weight packing ---------------------------------------------------------------------------
+enum OutMap : int { OUT_PLAIN = 0, OUT_D2S = 1, OUT_FINAL = 2 };
+struct PackArgs {
+    const float* w;    // [cout][cin][kh][kw] float32
+    void* dst;
+    int dtype;
+    int cout, cin, kh, kw;
+    int taps;          // packed taps (9 for conv3, 1 for GEMM1)
+    int nt, ntiles, nchunks;
+    int out_map;       // OutMap
+    int cq, cq_p;      // D2S: real / padded channels per output pixel
+    int in_map;        // SrcKind
+    int c0, cp0, c1;   // CONCAT: real/padded channels of in0, real channels of in1;  PLAIN/CRUSH: c0 = cin, cp0 = padded cin
+};
+size_t packed_bytes(int taps, int nt, int ntiles, int nchunks);
+hipError_t launch_pack(const PackArgs& a, hipStream_t s);
+
+// ---- small kernels ----------------------------------------------------------------------------
+// stem weights: float [cp][4] = {w0, w1, w2, bias}
+hipError_t launch_pack_stem(const float* w, const float* b, float* dst, int c, int cp, hipStream_t s);
+hipError_t launch_stem(int dtype, const void* x, const float* w4, void* out, int B, int H, int W, int cp,
+                       hipStream_t s);
+// zero rows >= Hv and columns >= Wv of an NHWC tensor [B,Hout,Wout,cp]
+hipError_t launch_zero_border(int dtype, void* t, int B, int Hout, int Wout, int cp, int Hv, int Wv,
+                              hipStream_t s);
+// qa[b][f] = bias[f] + mean_p feat[b][p][f]
+hipError_t launch_qa_reduce(int dtype, const void* feat, const float* bias, float* qa, int B, int P, int cp,
+                            int F, hipStream_t s);
+// layout helpers used by the operator-level tests
+hipError_t launch_fill_zero(void* p, size_t bytes, hipStream_t s);
+
+}  // namespace mz

@@ -1,0 +1,749 @@
+// gfx950 (MI355X / CDNA4) kernels of the MewZoom upscale path.
+//
+// Everything here is written for 64-wide wavefronts and the CDNA4 matrix cores:
+//   v_mfma_f32_32x32x16_{bf16,f16}  (8 K-elements per lane)  for the 16-bit modes
+//   v_mfma_f32_32x32x2_f32          (exact f32)              for the f32 verification mode
+//
+// Convolution = implicit GEMM computed TRANSPOSED: D[n][pixel] = sum_k W[n][k] * X[pixel][k].
+// The weight fragment is the MFMA "A" operand and the activation fragment the "B" operand, so an
+// accumulator register quad holds 4 CONSECUTIVE channels of one pixel (rows of a 32x32 tile are
+// (reg&3) + 8*(reg>>2) + 4*(lane>>5), the column = lane&31 = pixel): NHWC packing in the epilogue
+// needs no cross-lane traffic.
+//
+// LDS image of one K-stage (all sizes in bytes; a "chunk" is 32 bytes of channels per pixel, i.e.
+// 16 bf16/f16 channels or 8 f32 channels, split in two 16-byte "planes" = the two lane halves):
+//   A (activations)  CONV3: [plane 2][pixel 352 (10 rows x 34 cols halo, padded)][16]   = 11264
+//                    GEMM1: [chunk S][plane 2][pixel 256][16]                           = S*8192
+//   B (weights)      [chunk S][tap][nt][lane 64][16]  — already in fragment order in HBM, so a
+//                    stage is ONE contiguous run of TAPS*S*NT KiB copied by global_load_lds.
+// Both images are lane-linear, which is what global_load_lds (LDS-DMA) requires, and every
+// ds_read_b128 of a fragment covers contiguous 512-byte runs per half-wave: bank-conflict free.
+#include "mz_kernels.h"
+
+namespace mz {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+struct TF32 {
+    static constexpr int SZ = 4;
+    static constexpr int CK = 8;
+};
+struct TBF16 {
+    static constexpr int SZ = 2;
+    static constexpr int CK = 16;
+};
+struct TF16 {
+    static constexpr int SZ = 2;
+    static constexpr int CK = 16;
+};
+
+// ---- scalar conversions -----------------------------------------------------------------------
+template <class TT> __device__ __forceinline__ float ld1(const void* p);
+template <> __device__ __forceinline__ float ld1<TF32>(const void* p) { return *(const float*)p; }
+template <> __device__ __forceinline__ float ld1<TBF16>(const void* p) {
+    return __builtin_bit_cast(float, (uint32_t)(*(const uint16_t*)p) << 16);
+}
+template <> __device__ __forceinline__ float ld1<TF16>(const void* p) { return (float)(*(const _Float16*)p); }
+
+template <class TT> __device__ __forceinline__ void st1(void* p, float v);
+template <> __device__ __forceinline__ void st1<TF32>(void* p, float v) { *(float*)p = v; }
+template <> __device__ __forceinline__ void st1<TBF16>(void* p, float v) { *(__bf16*)p = (__bf16)v; }
+template <> __device__ __forceinline__ void st1<TF16>(void* p, float v) { *(_Float16*)p = (_Float16)v; }
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    uint16_t lo = __builtin_bit_cast(uint16_t, (__bf16)a);
+    uint16_t hi = __builtin_bit_cast(uint16_t, (__bf16)b);
+    return (uint32_t)lo | ((uint32_t)hi << 16);
+}
+__device__ __forceinline__ uint32_t pack_f16(float a, float b) {
+    uint16_t lo = __builtin_bit_cast(uint16_t, (_Float16)a);
+    uint16_t hi = __builtin_bit_cast(uint16_t, (_Float16)b);
+    return (uint32_t)lo | ((uint32_t)hi << 16);
+}
+
+// 4 consecutive channels <-> memory
+template <class TT> __device__ __forceinline__ void st4(void* p, const float v[4]);
+template <> __device__ __forceinline__ void st4<TF32>(void* p, const float v[4]) {
+    *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void st4<TBF16>(void* p, const float v[4]) {
+    *(uint2*)p = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+}
+template <> __device__ __forceinline__ void st4<TF16>(void* p, const float v[4]) {
+    *(uint2*)p = make_uint2(pack_f16(v[0], v[1]), pack_f16(v[2], v[3]));
+}
+template <class TT> __device__ __forceinline__ void ld4(const void* p, float v[4]);
+template <> __device__ __forceinline__ void ld4<TF32>(const void* p, float v[4]) {
+    float4 t = *(const float4*)p;
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ __forceinline__ void ld4<TBF16>(const void* p, float v[4]) {
+    uint2 t = *(const uint2*)p;
+    v[0] = __builtin_bit_cast(float, t.x << 16);
+    v[1] = __builtin_bit_cast(float, t.x & 0xffff0000u);
+    v[2] = __builtin_bit_cast(float, t.y << 16);
+    v[3] = __builtin_bit_cast(float, t.y & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void ld4<TF16>(const void* p, float v[4]) {
+    uint2 t = *(const uint2*)p;
+    v[0] = (float)__builtin_bit_cast(_Float16, (uint16_t)(t.x & 0xffff));
+    v[1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(t.x >> 16));
+    v[2] = (float)__builtin_bit_cast(_Float16, (uint16_t)(t.y & 0xffff));
+    v[3] = (float)__builtin_bit_cast(_Float16, (uint16_t)(t.y >> 16));
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+// ---- one K-chunk of matrix work: acc[n][pixel] += W[n][k] * X[pixel][k] ------------------------
+template <class TT> __device__ __forceinline__ void mma(f32x16& acc, const uint4& w, const uint4& x);
+template <> __device__ __forceinline__ void mma<TBF16>(f32x16& acc, const uint4& w, const uint4& x) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x),
+                                                  acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma<TF16>(f32x16& acc, const uint4& w, const uint4& x) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, w), __builtin_bit_cast(f16x8_t, x),
+                                                 acc, 0, 0, 0);
+}
+// f32: lane half h holds channels 4h..4h+3 of the 8-channel chunk; step e contracts {e, 4+e}.
+template <> __device__ __forceinline__ void mma<TF32>(f32x16& acc, const uint4& w, const uint4& x) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, w.x), __builtin_bit_cast(float, x.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, w.y), __builtin_bit_cast(float, x.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, w.z), __builtin_bit_cast(float, x.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, w.w), __builtin_bit_cast(float, x.w), acc, 0, 0, 0);
+}
+
+// LDS-DMA: 64 lanes x 16 bytes, per-lane global source, wave-uniform LDS destination.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// PyTorch's cubic convolution coefficients (A = -0.75), reference model.py:71 -> aten::upsample_bicubic2d
+__device__ __forceinline__ void cubic_coeffs(float t, float c[4]) {
+    const float A = -0.75f;
+    float x = t + 1.0f;
+    c[0] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
+    x = t;
+    c[1] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+    x = 1.0f - t;
+    c[2] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+    x = 2.0f - t;
+    c[3] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
+}
+
+// ================================================================================================
+// implicit-GEMM convolution
+// ================================================================================================
+template <int MODE> struct Geo;
+template <> struct Geo<MODE_CONV3> {
+    static constexpr int TAPS = 9;
+    static constexpr int S = 1;            // chunks per stage
+    static constexpr int A_ENT = 704;      // 16-byte entries per A image (2 planes x 352)
+    static constexpr int PLANE = 352 * 16;
+    static constexpr int MF_STRIDE = 34 * 16;  // second M fragment = next tile row
+};
+template <> struct Geo<MODE_GEMM1> {
+    static constexpr int TAPS = 1;
+    static constexpr int S = 3;
+    static constexpr int A_ENT = 3 * 512;
+    static constexpr int PLANE = 256 * 16;
+    static constexpr int MF_STRIDE = 32 * 16;
+};
+
+template <class TT, int NT, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
+    using G = Geo<MODE>;
+    constexpr int SZ = TT::SZ;
+    constexpr int TAPS = G::TAPS;
+    constexpr int S = G::S;
+    constexpr int BN = 32 * NT;
+    constexpr int A_BYTES = G::A_ENT * 16;
+    constexpr int B_PIECES = TAPS * S * NT;
+    constexpr int STAGE = A_BYTES + B_PIECES * 1024;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int r = lane & 31;
+
+    // ---- workgroup -> (pixel tile, N tile); consecutive logical ids share an XCD (and its L2) ----
+    int mtile, ntile;
+    {
+        const int nblk = a.mtiles * a.ntiles;
+        const int bid = blockIdx.x;
+        const int q = nblk >> 3, rem = nblk & 7, xcd = bid & 7, pos = bid >> 3;
+        const int L = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + pos;
+        if (a.n_fast) {
+            mtile = L / a.ntiles;
+            ntile = L - mtile * a.ntiles;
+        } else {
+            ntile = L / a.mtiles;
+            mtile = L - ntile * a.mtiles;
+        }
+    }
+    const int nbase = ntile * BN;
+    const char* wtile = (const char*)a.wpk + (size_t)ntile * a.nchunks * (TAPS * NT * 1024);
+
+    // ---- tile geometry ----
+    int b = 0, y0 = 0, x0 = 0;   // CONV3
+    long long m0 = 0;            // GEMM1
+    const long long M = (long long)a.B * a.Ho * a.Wo;
+    if (MODE == MODE_CONV3) {
+        const int tpi = a.tiles_x * a.tiles_y;
+        b = mtile / tpi;
+        const int rem = mtile - b * tpi;
+        const int ty = rem / a.tiles_x;
+        y0 = ty * 8;
+        x0 = (rem - ty * a.tiles_x) * 32;
+    } else {
+        m0 = (long long)mtile * 256;
+    }
+
+    // ---- per-thread staging sources (fixed for the whole K loop) ----
+    // CONV3: entries e = tid + 256*i of the halo image; GEMM1: pixel m0 + tid of both sources.
+    long long aoff[3];
+    if (MODE == MODE_CONV3) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int e = tid + 256 * i;
+            const int plane = e >= 352 ? 1 : 0;
+            const int p = e - plane * 352;
+            const int py = p / 34, px = p - py * 34;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            const bool ok = (e < 704) && (p < 340) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            aoff[i] = ok ? (((long long)b * a.H + gy) * a.W + gx) * a.cp0 * SZ + plane * 16 : -1;
+        }
+    } else {
+        const long long m = m0 + tid;
+        aoff[0] = aoff[1] = aoff[2] = -1;
+        if (m < M) {
+            if (a.src == SRC_CRUSH) {
+                const int ox = (int)(m % a.Wo);
+                const long long t = m / a.Wo;
+                const int oy = (int)(t % a.Ho);
+                const long long bb = t / a.Ho;
+                aoff[0] = ((bb * a.H + 2 * oy) * a.W + 2 * ox) * a.cp0 * SZ;
+            } else {
+                aoff[0] = m * a.cp0 * SZ;
+                aoff[1] = m * a.cp1 * SZ;
+            }
+        }
+    }
+
+    auto stage_load = [&](int st, int buf) {
+        char* Abuf = smem + buf * STAGE;
+        char* Bbuf = Abuf + A_BYTES;
+        // ---- weights: contiguous run of pieces, one KiB per wave-instruction ----
+        const int kc0 = st * S;
+        int npieces = B_PIECES;
+        if (MODE == MODE_GEMM1) {
+            const int left = a.nchunks - kc0;
+            if (left < S) npieces = left * NT;
+        }
+        const char* wsrc = wtile + (size_t)kc0 * (TAPS * NT * 1024);
+        for (int j = w; j < npieces; j += 4) {
+            if (a.use_glds) {
+                glds16(wsrc + j * 1024 + lane * 16, Bbuf + j * 1024);
+            } else {
+                *(uint4*)(Bbuf + j * 1024 + lane * 16) = *(const uint4*)(wsrc + j * 1024 + lane * 16);
+            }
+        }
+        // ---- activations ----
+        if (MODE == MODE_CONV3) {
+            const int kbyte = kc0 * 32;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (i == 2 && w == 3) break;  // entries 704.. do not exist
+                const char* src = aoff[i] >= 0 ? (const char*)a.in0 + aoff[i] + kbyte : (const char*)a.zero;
+                if (a.use_glds) {
+                    glds16(src, Abuf + (64 * w + 256 * i) * 16);
+                } else {
+                    *(uint4*)(Abuf + (tid + 256 * i) * 16) = *(const uint4*)src;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int kc = kc0 + s;
+                if (kc >= a.nchunks) break;
+                const char* base;
+                if (a.src == SRC_CRUSH) {
+                    const int tap = kc / a.nchunks0;
+                    const int cc = kc - tap * a.nchunks0;
+                    const long long toff = ((long long)(tap >> 1) * a.W + (tap & 1)) * a.cp0 * SZ + cc * 32;
+                    base = aoff[0] >= 0 ? (const char*)a.in0 + aoff[0] + toff : nullptr;
+                } else if (kc < a.nchunks0) {
+                    base = aoff[0] >= 0 ? (const char*)a.in0 + aoff[0] + kc * 32 : nullptr;
+                } else {
+                    base = aoff[1] >= 0 ? (const char*)a.in1 + aoff[1] + (kc - a.nchunks0) * 32 : nullptr;
+                }
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const char* src = base ? base + hh * 16 : (const char*)a.zero;
+                    char* dstw = Abuf + s * 8192 + hh * 4096 + (64 * w) * 16;
+                    if (a.use_glds) {
+                        glds16(src, dstw);
+                    } else {
+                        *(uint4*)(dstw + lane * 16) = *(const uint4*)src;
+                    }
+                }
+            }
+        }
+    };
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mf][nt][i] = 0.0f;
+
+    const int a_lane = (MODE == MODE_CONV3) ? h * G::PLANE + ((2 * w) * 34 + r) * 16
+                                            : h * G::PLANE + (64 * w + r) * 16;
+
+    const int nstages = (a.nchunks + S - 1) / S;
+    stage_load(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int st = 0; st < nstages; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < nstages) stage_load(st + 1, cur ^ 1);
+
+        const char* Ab = smem + cur * STAGE + a_lane;
+        const char* Bb = smem + cur * STAGE + A_BYTES + lane * 16;
+        int s_eff = S;
+        if (MODE == MODE_GEMM1) {
+            const int left = a.nchunks - st * S;
+            s_eff = left < S ? left : S;
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (s < s_eff) {
+#pragma unroll
+                for (int tap = 0; tap < TAPS; ++tap) {
+                    const int aofs = (MODE == MODE_CONV3) ? ((tap / 3) * 34 + (tap % 3)) * 16 : s * 8192;
+                    const uint4 xa = *(const uint4*)(Ab + aofs);
+                    const uint4 xb = *(const uint4*)(Ab + aofs + G::MF_STRIDE);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const uint4 wv = *(const uint4*)(Bb + ((s * TAPS + tap) * NT + nt) * 1024);
+                        mma<TT>(acc[0][nt], wv, xa);
+                        mma<TT>(acc[1][nt], wv, xb);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ============================== epilogue ==============================
+    // The staging buffers are free now (every wave is past the last barrier, no DMA in flight).
+    if (a.epi == EPI_FINAL) {
+        if (MODE == MODE_CONV3) {
+            constexpr int ROWF = 80;  // 16 floats + 16 bytes pad
+            char* ep = smem + w * (32 * ROWF);
+            const long long plane_i = (long long)a.Hi * a.Wi;
+            const long long plane_o = (long long)a.Hout * a.Wout;
+            for (int mf = 0; mf < 2; ++mf) {
+                const int y = y0 + 2 * w + mf;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[mf][0][4 * q + j];
+                    *(float4*)(ep + r * ROWF + (8 * q + 4 * h) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+                __syncthreads();
+                const int px = lane >> 1, jj = lane & 1;
+                const int x = x0 + px;
+                const int X = 2 * x + jj;
+                if (y < a.H && x < a.W) {
+                    // horizontal taps of this output column
+                    const int R = a.R;
+                    const int kx = X / R, phx = X - kx * R;
+                    const float sx = (phx + 0.5f) / (float)R - 0.5f;
+                    const int fx = sx < 0.0f ? -1 : 0;
+                    float cx[4];
+                    cubic_coeffs(sx - (float)fx, cx);
+                    int colx[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) colx[i] = min(max(kx + fx - 1 + i, 0), a.Wi - 1);
+#pragma unroll
+                    for (int i2 = 0; i2 < 2; ++i2) {
+                        const int Y = 2 * y + i2;
+                        const int ky = Y / R, phy = Y - ky * R;
+                        const float sy = (phy + 0.5f) / (float)R - 0.5f;
+                        const int fy = sy < 0.0f ? -1 : 0;
+                        float cy[4];
+                        cubic_coeffs(sy - (float)fy, cy);
+                        int rowy[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) rowy[i] = min(max(ky + fy - 1 + i, 0), a.Hi - 1);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const char* ip = (const char*)a.img + ((long long)b * 3 + c) * plane_i * SZ;
+                            float sres = 0.0f;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const char* rp = ip + (long long)rowy[i] * a.Wi * SZ;
+                                const float rowv = ld1<TT>(rp + colx[0] * SZ) * cx[0] + ld1<TT>(rp + colx[1] * SZ) * cx[1] +
+                                                   ld1<TT>(rp + colx[2] * SZ) * cx[2] + ld1<TT>(rp + colx[3] * SZ) * cx[3];
+                                sres += rowv * cy[i];
+                            }
+                            float v = sres + *(const float*)(ep + px * ROWF + ((2 * i2 + jj) * 4 + c) * 4);
+                            if (a.clamp) v = fminf(fmaxf(v, 0.0f), 1.0f);
+                            st1<TT>((char*)a.out + ((((long long)b * 3 + c) * plane_o) + (long long)Y * a.Wout + X) * SZ, v);
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        return;
+    }
+
+    constexpr int ROWB = BN * SZ + 16;
+    constexpr int UPP = BN * SZ / 16;  // 16-byte units per pixel row
+    constexpr int UPW = UPP / 2;       // units per lane (32 pixels * UPP / 64 lanes)
+    constexpr int EPU = 16 / SZ;       // channels per unit
+    char* ep = smem + w * (32 * ROWB);
+
+    for (int mf = 0; mf < 2; ++mf) {
+        // pixel owned by this lane in the accumulator layout
+        long long pix_acc = -1;  // linear pixel index in the (B,Ho,Wo) grid
+        if (MODE == MODE_CONV3) {
+            const int y = y0 + 2 * w + mf, x = x0 + r;
+            if (y < a.H && x < a.W) pix_acc = ((long long)b * a.H + y) * a.W + x;
+        } else {
+            const long long m = m0 + 64 * w + 32 * mf + r;
+            if (m < M) pix_acc = m;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[mf][nt][4 * q + j];
+                const int nloc = 32 * nt + 8 * q + 4 * h;
+                if (a.silu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] * sigmoidf_(v[j]);
+                }
+                if (a.epi == EPI_MIX) {
+                    float xv[4] = {0.f, 0.f, 0.f, 0.f}, zv[4] = {0.f, 0.f, 0.f, 0.f};
+                    const int n = nbase + nloc;
+                    if (pix_acc >= 0 && n < a.cp_out) {
+                        ld4<TT>((const char*)a.in0 + (pix_acc * a.cp0 + n) * SZ, xv);
+                        ld4<TT>((const char*)a.in1 + (pix_acc * a.cp1 + n) * SZ, zv);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = xv[j] + a.mix_scale * sigmoidf_(v[j]) * (zv[j] - xv[j]);
+                }
+                st4<TT>(ep + r * ROWB + nloc * SZ, v);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) {
+            const int u = lane + 64 * i;
+            const int px = u / UPP;
+            const int cu = u - px * UPP;
+            const uint4 val = *(const uint4*)(ep + px * ROWB + cu * 16);
+            const int n = nbase + cu * EPU;
+            if (MODE == MODE_CONV3) {
+                const int y = y0 + 2 * w + mf, x = x0 + px;
+                if (y < a.H && x < a.W) {
+                    if (a.epi == EPI_D2S) {
+                        if (n < 4 * a.cp_out) {
+                            const int ij = n / a.cp_out;
+                            const int c = n - ij * a.cp_out;
+                            const int Y = 2 * y + (ij >> 1), X = 2 * x + (ij & 1);
+                            *(uint4*)((char*)a.out + ((((long long)b * a.Hout + Y) * a.Wout + X) * a.cp_out + c) * SZ) = val;
+                        }
+                    } else if (n < a.cp_out) {
+                        *(uint4*)((char*)a.out + ((((long long)b * a.H + y) * a.W + x) * a.cp_out + n) * SZ) = val;
+                    }
+                }
+            } else {
+                const long long m = m0 + 64 * w + 32 * mf + px;
+                if (m < M && n < a.cp_out) *(uint4*)((char*)a.out + (m * a.cp_out + n) * SZ) = val;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+size_t conv_lds_bytes(int mode, int nt) {
+    const int taps = mode == MODE_CONV3 ? 9 : 1;
+    const int S = mode == MODE_CONV3 ? 1 : 3;
+    const int a_bytes = (mode == MODE_CONV3 ? 704 : 3 * 512) * 16;
+    const size_t staging = 2 * (size_t)(a_bytes + taps * S * nt * 1024);
+    const size_t epi = 4 * 32 * (size_t)(32 * nt * 4 + 16);
+    return staging > epi ? staging : epi;
+}
+
+int choose_nt(int n_padded) {
+    // smallest padded N wins; ties prefer 3, 2, 4, 1 (4 needs 94 KiB of LDS: one workgroup per CU)
+    const int order[4] = {3, 2, 4, 1};
+    int best = 1, best_n = 1 << 30;
+    for (int i = 0; i < 4; ++i) {
+        const int bn = 32 * order[i];
+        const int padded = (n_padded + bn - 1) / bn * bn;
+        if (padded < best_n) {
+            best_n = padded;
+            best = order[i];
+        }
+    }
+    return best;
+}
+
+template <class TT, int NT, int MODE> static hipError_t launch_one(const ConvArgs& a, hipStream_t s) {
+    const size_t lds = conv_lds_bytes(MODE, NT);
+    hipLaunchKernelGGL((conv_kernel<TT, NT, MODE>), dim3(a.mtiles * a.ntiles), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+template <class TT, int MODE> static hipError_t launch_nt(int nt, const ConvArgs& a, hipStream_t s) {
+    switch (nt) {
+        case 1: return launch_one<TT, 1, MODE>(a, s);
+        case 2: return launch_one<TT, 2, MODE>(a, s);
+        case 3: return launch_one<TT, 3, MODE>(a, s);
+        case 4: return launch_one<TT, 4, MODE>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+template <class TT> static hipError_t launch_mode(int mode, int nt, const ConvArgs& a, hipStream_t s) {
+    return mode == MODE_CONV3 ? launch_nt<TT, MODE_CONV3>(nt, a, s) : launch_nt<TT, MODE_GEMM1>(nt, a, s);
+}
+hipError_t launch_conv(int dtype, int mode, int nt, const ConvArgs& a, hipStream_t s) {
+    if (a.mtiles <= 0 || a.ntiles <= 0) return hipErrorInvalidValue;
+    switch (dtype) {
+        case DT_F32: return launch_mode<TF32>(mode, nt, a, s);
+        case DT_BF16: return launch_mode<TBF16>(mode, nt, a, s);
+        case DT_F16: return launch_mode<TF16>(mode, nt, a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <class TT, int NT, int MODE> static hipError_t set_lds_one() {
+    return hipFuncSetAttribute((const void*)conv_kernel<TT, NT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)conv_lds_bytes(MODE, NT));
+}
+template <class TT> static hipError_t set_lds_all() {
+    hipError_t e;
+#define MZ_SET(NT, MODE) \
+    if ((e = set_lds_one<TT, NT, MODE>()) != hipSuccess) return e;
+    MZ_SET(1, MODE_CONV3) MZ_SET(2, MODE_CONV3) MZ_SET(3, MODE_CONV3) MZ_SET(4, MODE_CONV3)
+    MZ_SET(1, MODE_GEMM1) MZ_SET(2, MODE_GEMM1) MZ_SET(3, MODE_GEMM1) MZ_SET(4, MODE_GEMM1)
+#undef MZ_SET
+    return hipSuccess;
+}
+hipError_t init_kernels() {
+    hipError_t e;
+    if ((e = set_lds_all<TF32>()) != hipSuccess) return e;
+    if ((e = set_lds_all<TBF16>()) != hipSuccess) return e;
+    return set_lds_all<TF16>();
+}
+
+// ================================================================================================
+// weight packing: OIHW float32 -> [ntile][kchunk][tap][nt][lane][16 bytes] in the compute dtype
+// ================================================================================================
+template <class TT> __global__ void pack_kernel(const PackArgs a, long long total) {
+    constexpr int SZ = TT::SZ;
+    constexpr int CK = TT::CK;
+    constexpr int EPL = 16 / SZ;  // elements per lane
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    long long t = idx;
+    const int e = (int)(t % EPL); t /= EPL;
+    const int lane = (int)(t % 64); t /= 64;
+    const int nt = (int)(t % a.nt); t /= a.nt;
+    const int tap = (int)(t % a.taps); t /= a.taps;
+    const int kc = (int)(t % a.nchunks); t /= a.nchunks;
+    const int nb = (int)t;
+    const int n = (nb * a.nt + nt) * 32 + (lane & 31);
+    const int hh = lane >> 5;
+    const int kin = hh * (CK / 2) + e;  // channel within the chunk
+
+    // output channel
+    int o = -1;
+    if (a.out_map == OUT_PLAIN) {
+        o = n < a.cout ? n : -1;
+    } else if (a.out_map == OUT_D2S) {
+        const int ij = n / a.cq_p, c = n - ij * a.cq_p;
+        o = (ij < 4 && c < a.cq) ? c * 4 + ij : -1;  // PixelShuffle(2): in-channel = c*4 + 2i + j
+    } else {
+        const int ij = n >> 2, c = n & 3;
+        o = (n < 16 && c < 3) ? c * 4 + ij : -1;
+    }
+    // input channel and filter tap
+    int ci = -1, ty = 0, tx = 0;
+    if (a.in_map == SRC_PLAIN) {
+        const int k = kc * CK + kin;
+        ci = k < a.c0 ? k : -1;
+        ty = tap / a.kw;
+        tx = tap - ty * a.kw;
+    } else if (a.in_map == SRC_CONCAT) {
+        const int k = kc * CK + kin;
+        if (k < a.cp0) ci = k < a.c0 ? k : -1;
+        else ci = (k - a.cp0) < a.c1 ? a.c0 + (k - a.cp0) : -1;
+    } else {  // CRUSH: K axis = [tap][padded channel]
+        const int cpt = a.cp0 / CK;  // chunks per tap
+        const int st = kc / cpt;
+        const int k = (kc - st * cpt) * CK + kin;
+        ci = k < a.c0 ? k : -1;
+        ty = st >> 1;
+        tx = st & 1;
+    }
+    float v = 0.0f;
+    if (o >= 0 && ci >= 0) v = a.w[(((long long)o * a.cin + ci) * a.kh + ty) * a.kw + tx];
+    st1<TT>((char*)a.dst + idx * SZ, v);
+}
+
+size_t packed_bytes(int taps, int nt, int ntiles, int nchunks) {
+    return (size_t)ntiles * nchunks * taps * nt * 1024;
+}
+
+hipError_t launch_pack(const PackArgs& a, hipStream_t s) {
+    const int sz = dtype_size(a.dtype);
+    const long long total = (long long)packed_bytes(a.taps, a.nt, a.ntiles, a.nchunks) / sz;
+    const int blocks = (int)((total + 255) / 256);
+    switch (a.dtype) {
+        case DT_F32: hipLaunchKernelGGL(pack_kernel<TF32>, dim3(blocks), dim3(256), 0, s, a, total); break;
+        case DT_BF16: hipLaunchKernelGGL(pack_kernel<TBF16>, dim3(blocks), dim3(256), 0, s, a, total); break;
+        case DT_F16: hipLaunchKernelGGL(pack_kernel<TF16>, dim3(blocks), dim3(256), 0, s, a, total); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ================================================================================================
+// small kernels
+// ================================================================================================
+__global__ void pack_stem_kernel(const float* w, const float* b, float* dst, int c, int cp) {
+    // dst: float4 per channel {w0, w1, w2, bias}; zero-initialised by the caller; either of w / b may be null
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cp) return;
+    float4 v = ((float4*)dst)[i];
+    if (i < c) {
+        if (w) { v.x = w[i * 3 + 0]; v.y = w[i * 3 + 1]; v.z = w[i * 3 + 2]; }
+        if (b) v.w = b[i];
+    } else {
+        v = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    ((float4*)dst)[i] = v;
+}
+hipError_t launch_pack_stem(const float* w, const float* b, float* dst, int c, int cp, hipStream_t s) {
+    hipLaunchKernelGGL(pack_stem_kernel, dim3((cp + 63) / 64), dim3(64), 0, s, w, b, dst, c, cp);
+    return hipGetLastError();
+}
+
+// FanOutProjection (reference model.py:239-242): per-pixel 3 -> C affine, NCHW image -> NHWC features.
+template <class TT> __global__ void stem_kernel(const void* x, const float4* w4, void* out, long long npix, long long HW,
+                                                int cp) {
+    constexpr int SZ = TT::SZ;
+    const int groups = cp / 8;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix * groups) return;
+    const long long pix = idx / groups;
+    const int g = (int)(idx - pix * groups);
+    const long long b = pix / HW, p = pix - b * HW;
+    const char* xp = (const char*)x + (b * 3 * HW + p) * SZ;
+    const float r0 = ld1<TT>(xp), r1 = ld1<TT>(xp + HW * SZ), r2 = ld1<TT>(xp + 2 * HW * SZ);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float4 wv = w4[g * 8 + j];
+        v[j] = wv.w + wv.x * r0 + wv.y * r1 + wv.z * r2;
+    }
+    char* op = (char*)out + (pix * cp + g * 8) * SZ;
+    st4<TT>(op, v);
+    st4<TT>(op + 4 * SZ, v + 4);
+}
+hipError_t launch_stem(int dtype, const void* x, const float* w4, void* out, int B, int H, int W, int cp, hipStream_t s) {
+    const long long HW = (long long)H * W, npix = HW * B;
+    const long long total = npix * (cp / 8);
+    const int blocks = (int)((total + 255) / 256);
+    switch (dtype) {
+        case DT_F32: hipLaunchKernelGGL(stem_kernel<TF32>, dim3(blocks), dim3(256), 0, s, x, (const float4*)w4, out, npix, HW, cp); break;
+        case DT_BF16: hipLaunchKernelGGL(stem_kernel<TBF16>, dim3(blocks), dim3(256), 0, s, x, (const float4*)w4, out, npix, HW, cp); break;
+        case DT_F16: hipLaunchKernelGGL(stem_kernel<TF16>, dim3(blocks), dim3(256), 0, s, x, (const float4*)w4, out, npix, HW, cp); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// Decoder.crop_feature_maps zero padding (reference model.py:667-673, 681-687): bottom rows / right columns.
+__global__ void zero_border_kernel(char* t, int B, int Hout, int Wout, int rowbytes16, int Hv, int Wv) {
+    // one thread per 16-byte unit of a border pixel; border pixels: rows >= Hv (all columns) and cols >= Wv (rows < Hv)
+    const long long nb_rows = (long long)(Hout - Hv) * Wout;
+    const long long nb_cols = (long long)Hv * (Wout - Wv);
+    const long long per_img = nb_rows + nb_cols;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = per_img * B * rowbytes16;
+    if (idx >= total) return;
+    const int u = (int)(idx % rowbytes16);
+    long long pb = idx / rowbytes16;
+    const long long b = pb / per_img;
+    long long k = pb - b * per_img;
+    int y, x;
+    if (k < nb_rows) {
+        y = Hv + (int)(k / Wout);
+        x = (int)(k % Wout);
+    } else {
+        k -= nb_rows;
+        const int wc = Wout - Wv;
+        y = (int)(k / wc);
+        x = Wv + (int)(k % wc);
+    }
+    *(uint4*)(t + ((((long long)b * Hout + y) * Wout + x) * rowbytes16 + u) * 16) = make_uint4(0, 0, 0, 0);
+}
+hipError_t launch_zero_border(int dtype, void* t, int B, int Hout, int Wout, int cp, int Hv, int Wv, hipStream_t s) {
+    if (Hv >= Hout && Wv >= Wout) return hipSuccess;
+    const int rb16 = cp * dtype_size(dtype) / 16;
+    const long long per_img = (long long)(Hout - Hv) * Wout + (long long)Hv * (Wout - Wv);
+    const long long total = per_img * B * rb16;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(zero_border_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (char*)t, B, Hout, Wout,
+                       rb16, Hv, Wv);
+    return hipGetLastError();
+}
+
+// QualityAssessor pooling (reference model.py:1028-1030): spatial mean of the conv output, plus the conv bias.
+template <class TT> __global__ void qa_reduce_kernel(const void* feat, const float* bias, float* qa, int P, int cp, int F) {
+    constexpr int SZ = TT::SZ;
+    __shared__ float red[256];
+    const int b = blockIdx.x, f = blockIdx.y;
+    const char* base = (const char*)feat + ((long long)b * P * cp + f) * SZ;
+    float sum = 0.0f;
+    for (int p = threadIdx.x; p < P; p += 256) sum += ld1<TT>(base + (long long)p * cp * SZ);
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) qa[b * F + f] = red[0] / (float)P + bias[f];
+}
+hipError_t launch_qa_reduce(int dtype, const void* feat, const float* bias, float* qa, int B, int P, int cp, int F,
+                            hipStream_t s) {
+    switch (dtype) {
+        case DT_F32: hipLaunchKernelGGL(qa_reduce_kernel<TF32>, dim3(B, F), dim3(256), 0, s, feat, bias, qa, P, cp, F); break;
+        case DT_BF16: hipLaunchKernelGGL(qa_reduce_kernel<TBF16>, dim3(B, F), dim3(256), 0, s, feat, bias, qa, P, cp, F); break;
+        case DT_F16: hipLaunchKernelGGL(qa_reduce_kernel<TF16>, dim3(B, F), dim3(256), 0, s, feat, bias, qa, P, cp, F); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_zero(void* p, size_t bytes, hipStream_t s) { return hipMemsetAsync(p, 0, bytes, s); }
+
+}  // namespace mz

@@ -1,0 +1,319 @@
+"""Drop-in ``MewZoom`` whose forward pass runs on the hand-written gfx950 kernels.
+
+Mirrors the Python interface of the reference model (src/ultrazoom/model.py:43-192 of
+andrewdalpino/UltraZoom v0.3.0): same constructor keyword arguments, same ``state_dict`` key names
+and shapes (so ``PyTorchModelHubMixin.from_pretrained`` / ``load_state_dict`` work unchanged), same
+``forward`` / ``upscale`` / ``predict_degredation`` methods, same ``AssertionError``s.
+
+The module tree below only HOLDS parameters; it contains no PyTorch arithmetic.  All compute goes
+through the C ABI of ``libmewzoom_hip.so``.  There is no CPU or eager-PyTorch fallback: calling the
+model with a non-GPU tensor raises.
+"""
+
+from __future__ import annotations
+
+import math
+from math import ceil, floor, log2
+from typing import Dict, Iterable, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+from huggingface_hub import PyTorchModelHubMixin
+
+from . import _ffi
+
+
+# --------------------------------------------------------------------------------------------
+# parameter containers (names match the reference module tree)
+# --------------------------------------------------------------------------------------------
+class _ConvParams(nn.Module):
+    """Holds ``weight`` (and optionally ``bias``) of a Conv2d; never called."""
+
+    def __init__(self, cin: int, cout: int, k: int, bias: bool = False):
+        super().__init__()
+        assert cin > 0, "Input channels must be greater than 0."
+        assert cout > 0, "Output channels must be greater than 0."
+        w = torch.empty(cout, cin, k, k)
+        bound = 1.0 / math.sqrt(cin * k * k)
+        nn.init.uniform_(w, -bound, bound)  # same distribution as torch's Conv2d default
+        self.weight = nn.Parameter(w)
+        if bias:
+            self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
+
+
+class _Holder(nn.Module):
+    """A module with a single ``conv`` child, e.g. ``stem.conv`` / ``downsample1.conv``."""
+
+    def __init__(self, cin: int, cout: int, k: int, bias: bool = False):
+        super().__init__()
+        self.conv = _ConvParams(cin, cout, k, bias)
+
+
+class _MixParams(nn.Module):  # AdaptiveResidualMix, model.py:795-839
+    def __init__(self, c: int):
+        super().__init__()
+        self.conv = _ConvParams(2 * c, c, 1)
+        self.alpha = nn.Parameter(torch.tensor(0.0))
+
+
+class _BottleneckParams(nn.Module):  # InvertedBottleneck, model.py:731-778
+    def __init__(self, c: int, hidden_ratio: int):
+        super().__init__()
+        assert c > 0, "Number of channels must be greater than 0."
+        assert hidden_ratio in {1, 2, 4}, "Hidden ratio must be either 1, 2, or 4."
+        self.conv1 = _ConvParams(c, hidden_ratio * c, 3)
+        self.conv2 = _ConvParams(hidden_ratio * c, c, 3)
+
+
+class _BlockParams(nn.Module):  # EncoderBlock / DecoderBlock, model.py:487-511
+    def __init__(self, c: int, hidden_ratio: int):
+        super().__init__()
+        self.convnet = _BottleneckParams(c, hidden_ratio)
+        self.skip = _MixParams(c)
+
+
+def _stage(c: int, n: int, hr: int) -> nn.ModuleList:
+    return nn.ModuleList([_BlockParams(c, hr) for _ in range(n)])
+
+
+class _EncoderParams(nn.Module):  # model.py:326-392
+    def __init__(self, ch, layers, hr, num_deg_features):
+        super().__init__()
+        names = ("primary", "secondary", "tertiary", "quaternary")
+        for n, l in zip(names, layers):
+            assert l > 0, f"Number of {n} layers must be greater than 0."
+        assert num_deg_features > 0, "Number of quality assessor features must be greater than 0."
+        for i in range(4):
+            setattr(self, f"stage{i + 1}", _stage(ch[i], layers[i], hr))
+        for i in range(3):
+            setattr(self, f"downsample{i + 1}", _Holder(ch[i], ch[i + 1], 2))
+        self.qa_head = _Holder(ch[3], num_deg_features, 3, bias=True)
+
+
+class _DecoderParams(nn.Module):  # model.py:514-575; stage1 is the coarsest level
+    def __init__(self, ch, layers, hr):
+        super().__init__()
+        for i in range(4):
+            setattr(self, f"stage{i + 1}", _stage(ch[3 - i], layers[3 - i], hr))
+        for i in range(3):
+            setattr(self, f"upsample{i + 1}", _Holder(ch[3 - i], 4 * ch[2 - i], 3))
+        for i in range(3):
+            setattr(self, f"skip{i + 1}", _MixParams(ch[2 - i]))
+
+
+class _UNetParams(nn.Module):  # model.py:245-300
+    def __init__(self, ch, layers, hr, num_deg_features):
+        super().__init__()
+        names = ("primary", "secondary", "tertiary", "quaternary")
+        for n, l in zip(names, layers):
+            assert l > 1, f"Number of {n} layers must be greater than 1."
+        self.encoder = _EncoderParams(ch, [ceil(l / 2) for l in layers], hr, num_deg_features)
+        self.decoder = _DecoderParams(ch, [floor(l / 2) for l in layers], hr)
+
+
+class _SR2XParams(nn.Module):  # SR2XBlock, model.py:975-983
+    def __init__(self, c: int, hr: int, cout: int):
+        super().__init__()
+        self.refiner = _BlockParams(c, hr)
+        self.upscale = _Holder(c, 4 * cout, 3)
+
+
+class _HeadParams(nn.Module):  # SuperResolver, model.py:933-954
+    def __init__(self, c: int, hr: int, ratio: int):
+        super().__init__()
+        assert ratio in {2, 4, 8}, "Upscale ratio must be either 2, 4, or 8."
+        n = int(log2(ratio))
+        self.layers = nn.ModuleList([_SR2XParams(c, hr, c) for _ in range(n - 1)] + [_SR2XParams(c, hr, 3)])
+
+
+# --------------------------------------------------------------------------------------------
+# the model
+# --------------------------------------------------------------------------------------------
+class MewZoom(nn.Module, PyTorchModelHubMixin):
+    """Image super-resolution U-Net with adaptive residual connections, computed on MI355X.
+
+    Constructor arguments are the reference's (model.py:51-64).
+    """
+
+    AVAILABLE_UPSCALE_RATIOS = {2, 4, 8}
+
+    def __init__(
+        self,
+        upscale_ratio: int,
+        primary_channels: int,
+        primary_layers: int,
+        secondary_channels: int,
+        secondary_layers: int,
+        tertiary_channels: int,
+        tertiary_layers: int,
+        quaternary_channels: int,
+        quaternary_layers: int,
+        hidden_ratio: int,
+        num_deg_features: int,
+    ):
+        super().__init__()
+
+        assert (
+            upscale_ratio in self.AVAILABLE_UPSCALE_RATIOS
+        ), f"Upscale ratio must be one of {self.AVAILABLE_UPSCALE_RATIOS}, but got {upscale_ratio}."
+        assert 3 < primary_channels, "Output channels must be greater than input channels."
+
+        self._cfg = dict(
+            upscale_ratio=upscale_ratio,
+            primary_channels=primary_channels,
+            primary_layers=primary_layers,
+            secondary_channels=secondary_channels,
+            secondary_layers=secondary_layers,
+            tertiary_channels=tertiary_channels,
+            tertiary_layers=tertiary_layers,
+            quaternary_channels=quaternary_channels,
+            quaternary_layers=quaternary_layers,
+            hidden_ratio=hidden_ratio,
+            num_deg_features=num_deg_features,
+        )
+        ch = (primary_channels, secondary_channels, tertiary_channels, quaternary_channels)
+        layers = (primary_layers, secondary_layers, tertiary_layers, quaternary_layers)
+
+        self.stem = _Holder(3, primary_channels, 1, bias=True)
+        self.unet = _UNetParams(ch, layers, hidden_ratio, num_deg_features)
+        self.head = _HeadParams(primary_channels, hidden_ratio, upscale_ratio)
+        self.upscale_ratio = upscale_ratio
+
+        # how many images of a batch are in flight at once inside the library (0 = its default)
+        self.max_images_in_flight = 0
+        self._engine: Optional[_Engine] = None
+
+    # ---- bookkeeping identical to the reference -------------------------------------------
+    @property
+    def num_params(self) -> int:
+        return sum(p.numel() for p in self.parameters())
+
+    @property
+    def num_trainable_params(self) -> int:
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+    def freeze_parameters(self) -> None:
+        for p in self.parameters():
+            p.requires_grad = False
+
+    # ---- engine management ------------------------------------------------------------------
+    def _weights_signature(self) -> Tuple:
+        return tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in self.parameters())
+
+    def _get_engine(self, x: Tensor) -> "_Engine":
+        if not x.is_cuda:
+            raise RuntimeError(
+                "ultrazoom_amd.MewZoom computes on an MI355X only: move the model and the input to a 'cuda' device. "
+                "There is no CPU path."
+            )
+        p0 = next(self.parameters())
+        if p0.device != x.device:
+            raise RuntimeError(f"model is on {p0.device} but the input is on {x.device}")
+        if x.dtype != p0.dtype:
+            raise RuntimeError(f"Input type ({x.dtype}) and weight type ({p0.dtype}) should be the same")
+        sig = self._weights_signature()
+        if self._engine is None or self._engine.signature != sig:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = _Engine(self._cfg, self.state_dict(), p0.dtype, x.device, sig)
+        return self._engine
+
+    def _run(self, x: Tensor, clamp: bool, want_qa: bool):
+        assert x.dim() == 4 and x.shape[1] == 3, "expected a (B, 3, H, W) tensor"
+        engine = self._get_engine(x)
+        return engine.run(x.contiguous(), clamp, want_qa, self.max_images_in_flight)
+
+    # ---- the reference's public methods -----------------------------------------------------
+    def forward(self, x: Tensor) -> Tuple[Tensor, Tensor]:
+        """Returns ``(s + z, z_qa)``: the un-clamped super-resolved image and the degradation features
+        (model.py:149-164).  Inference only: no autograd graph is recorded."""
+        sr, qa = self._run(x, clamp=False, want_qa=True)
+        return sr, qa.to(x.dtype)
+
+    @torch.inference_mode()
+    def upscale(self, x: Tensor) -> Tensor:
+        """``clamp(forward(x)[0], 0, 1)`` (model.py:166-179); the quality head is skipped."""
+        sr, _ = self._run(x, clamp=True, want_qa=False)
+        return sr
+
+    @torch.inference_mode()
+    def predict_degredation(self, x: Tensor) -> Tensor:  # (sic) model.py:181-192
+        _, qa = self._run(x, clamp=False, want_qa=True)
+        return qa.to(x.dtype)
+
+    # ---- checkpoint ingestion (test_compare.py:32-45 of the reference) -------------------------
+    def load_training_checkpoint(self, state_dict: Dict[str, Tensor]) -> None:
+        """Loads a raw training checkpoint: strips ``_orig_mod.`` prefixes left by torch.compile and
+        bakes weight-norm parametrisations (w = g * v / ||v||, norm over all dims but 0) into plain
+        ``conv.weight`` tensors, which is what the reference does with ``add_weight_norms`` ->
+        ``load_state_dict`` -> ``remove_parameterizations``."""
+        self.load_state_dict(bake_state_dict(state_dict))
+
+
+def bake_state_dict(state_dict: Dict[str, Tensor]) -> Dict[str, Tensor]:
+    """Turns a training-time state_dict into the baked layout this model (and the HF export) uses."""
+    sd = {k.replace("_orig_mod.", ""): v for k, v in state_dict.items()}
+    out: Dict[str, Tensor] = {}
+    g_suffix = ".parametrizations.weight.original0"
+    v_suffix = ".parametrizations.weight.original1"
+    for k, v in sd.items():
+        if k.endswith(g_suffix):
+            base = k[: -len(g_suffix)]
+            g = v
+            vv = sd[base + v_suffix]
+            norm = vv.flatten(1).norm(dim=1).reshape(-1, *([1] * (vv.dim() - 1)))
+            out[base + ".weight"] = g * vv / norm
+        elif k.endswith(v_suffix):
+            continue
+        else:
+            out[k] = v
+    return out
+
+
+class _Engine:
+    """One mz_handle plus its packed weights and cached workspaces for a (dtype, device)."""
+
+    def __init__(self, config: dict, state_dict: Dict[str, Tensor], dtype, device, signature):
+        self.signature = signature
+        self.dtype = dtype
+        self.device = device
+        self.handle = _ffi.Handle(config, _ffi.dtype_code(dtype))
+        self.config = config
+        self._workspace: Optional[Tensor] = None
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device)
+            names = dict(self.handle.weight_infos())
+            missing = [k for k in names if k not in state_dict]
+            if missing:
+                raise KeyError(f"state_dict lacks {missing[:3]} ...")
+            for name, shape in names.items():
+                t = state_dict[name].detach()
+                if tuple(t.shape) != shape:
+                    raise ValueError(f"{name}: shape {tuple(t.shape)} != expected {shape}")
+                t32 = t.to(device=device, dtype=torch.float32).contiguous()
+                self.handle.set_weight(name, t32.data_ptr(), shape, stream.cuda_stream)
+                # keep t32 alive until the packing kernel has consumed it
+                t32.record_stream(stream)
+            self.handle.weights_complete()
+            stream.synchronize()
+
+    def close(self) -> None:
+        self.handle.close()
+        self._workspace = None
+
+    def run(self, x: Tensor, clamp: bool, want_qa: bool, max_in_flight: int):
+        B, _, H, W = x.shape
+        r = self.config["upscale_ratio"]
+        with torch.cuda.device(self.device):
+            need = self.handle.workspace_bytes(B, H, W, max_in_flight)
+            if self._workspace is None or self._workspace.numel() < need:
+                self._workspace = None
+                self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+            sr = torch.empty((B, 3, H * r, W * r), dtype=self.dtype, device=self.device)
+            qa = torch.empty((B, self.config["num_deg_features"]), dtype=torch.float32, device=self.device) if want_qa else None
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            self.handle.forward(
+                x.data_ptr(), sr.data_ptr(), qa.data_ptr() if want_qa else 0, B, H, W, clamp,
+                self._workspace.data_ptr(), self._workspace.numel(), max_in_flight, stream,
+            )
+        return sr, qa
