@@ -64,13 +64,31 @@ def parameter_shapes(cfg):
     return {k: tuple(v.shape) for k, v in m.state_dict().items()}
 
 
+def host_cores() -> int:
+    """CPU cores this process may really use: affinity mask and cgroup quota, not the machine's core count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    if "MZ_CPU_THREADS" in os.environ:
+        n = int(os.environ["MZ_CPU_THREADS"])
+    return max(1, n)
+
+
 def cpu_baseline(cfg, sd, model, dtype, sample_hw):
     """Times the CPU oracle on a bounded sample and checks the GPU result against it."""
     from oracle import mewzoom_oracle as oracle  # checker / baseline only
 
     h, w = sample_hw
     x = synth_image(1, h, w, seed=99)
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     with torch.inference_mode():
         oracle.upscale(cfg, sd, x[:, :, : h // 2, : w // 2])  # warm-up (thread pool, allocator)
@@ -107,6 +125,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=list(DTYPES))
     ap.add_argument("--images-in-flight", type=int, default=0, help="micro-batch inside the library (0 = default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-launches", default="", help="write a per-launch CSV (shape, ms, TFLOP/s) of the profiled step")
     ap.add_argument("--no-gather", action="store_true", help="skip the output gather in the timed step (N > 1)")
     args = ap.parse_args()
 
@@ -172,6 +191,8 @@ def main():
         engine.handle.profile_enable(True)
         model.upscale(x)
         torch.cuda.synchronize(device)
+        if args.dump_launches:
+            engine.handle.profile_dump(args.dump_launches)
         prof = engine.handle.profile_read()
         engine.handle.profile_enable(False)
         conv_tflops = prof["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12 if prof["conv_ms"] > 0 else 0.0

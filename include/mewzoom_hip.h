@@ -134,6 +134,8 @@ double mz_flops_per_image(const mz_handle* h, int H, int W);
 /* Enables per-kernel HIP-event timing for bench.py's live roofline leg: after a forward, returns the
  * accumulated device time (ms) and FLOPs of all conv3x3 implicit-GEMM launches since the last reset. */
 int mz_profile_enable(mz_handle* h, int on);
+/* Writes one CSV row per profiled launch (layer shape, device ms, TFLOP/s) — tuning aid. */
+int mz_profile_dump(mz_handle* h, const char* path);
 int mz_profile_read(mz_handle* h, double* conv_ms, double* conv_flops, double* conv_launches,
                     double* other_ms, double* conv_bytes);
 

@@ -65,6 +65,8 @@ def _declare(lib) -> None:
     lib.mz_flops_per_image.restype = c_double
     lib.mz_profile_enable.argtypes = [H, c_int]
     lib.mz_profile_read.argtypes = [H] + [POINTER(c_double)] * 5
+    lib.mz_profile_dump.argtypes = [H, c_char_p]
+    lib.mz_profile_dump.restype = c_int
     for name in (
         "mz_create mz_destroy mz_num_weights mz_weight_info mz_set_weight mz_weights_complete mz_workspace_bytes "
         "mz_forward mz_padded_channels mz_op_conv mz_op_stem mz_op_final mz_profile_enable mz_profile_read"
@@ -161,6 +163,9 @@ class Handle:
 
     def profile_enable(self, on: bool) -> None:
         check(lib().mz_profile_enable(self._h, int(on)))
+
+    def profile_dump(self, path: str) -> None:
+        check(lib().mz_profile_dump(self._h, str(path).encode()))
 
     def profile_read(self) -> dict:
         vals = [c_double() for _ in range(5)]

@@ -55,7 +55,7 @@ struct ConvW {
     // logical (reference) shape
     int cout = 0, cin = 0, kh = 0, kw = 0;
     // kernel selection
-    int mode = MODE_CONV3, taps = 9, nt = 1, ntiles = 1, nchunks = 1;
+    int mode = MODE_CONV3, taps = 9, nt = 1, ntiles = 1, nchunks = 1, nchunks_real = 1;
     int out_map = OUT_PLAIN, cq = 0, cq_p = 0;
     int in_map = SRC_PLAIN, c0 = 0, cp0 = 0, c1 = 0;
     int n_logical_padded = 0;
@@ -93,6 +93,8 @@ static void plan_conv(ConvW& c, int dtype, int mode, int cout, int cin, int kh, 
         c.c0 = cin; c.cp0 = pad16(cin); c.c1 = 0;
         c.nchunks = 4 * c.cp0 / ck;
     }
+    c.nchunks_real = c.nchunks;
+    if (mode == MODE_GEMM1) c.nchunks = (c.nchunks + 2) / 3 * 3;  // the 1x1 kernel consumes 3 chunks per stage
     c.packed_sz = packed_bytes(c.taps, c.nt, c.ntiles, c.nchunks);
 }
 
@@ -118,6 +120,7 @@ struct ProfRec {
     hipEvent_t a, b;
     double flops, bytes;
     int is_conv3;
+    int kind, B, H, W, cin, cout, nt, ntiles, mtiles, n_fast;  // kind: 0 conv3, 1 mix, 2 crush
 };
 
 struct mz_handle {
@@ -465,6 +468,7 @@ struct Runner {
         }
         r = &h->recs[h->recs_used++];
         r->flops = flops; r->bytes = bytes; r->is_conv3 = is_conv3;
+        r->kind = r->B = r->H = r->W = r->cin = r->cout = r->nt = r->ntiles = r->mtiles = r->n_fast = 0;
         (void)hipEventRecord(r->a, s);
     }
     void prof_end(ProfRec* r) {
@@ -481,6 +485,7 @@ struct Runner {
         a.wpk = c.packed;
         a.zero = h ? h->zero_page : nullptr;
         a.nchunks = c.nchunks;
+        a.nchunks_real = c.nchunks_real;
         a.ntiles = c.ntiles;
         a.use_glds = h ? h->use_glds : 1;
     }
@@ -516,6 +521,7 @@ struct Runner {
         pick_order(a, c, px * c.cp0 * sz);
         ProfRec* r;
         prof_begin(r, 2.0 * px * 9.0 * c.cin * c.cout, px * (c.cin + c.cout) * sz + 9.0 * c.cin * c.cout * sz, 1);
+        if (r) { r->kind = 0; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.n_fast; }
         check(launch_conv(dtype, MODE_CONV3, c.nt, a, s), "conv3x3 launch");
         prof_end(r);
     }
@@ -542,6 +548,7 @@ struct Runner {
         pick_order(a, c, (double)npix * (a.cp0 + a.cp1) * sz);
         ProfRec* r;
         prof_begin(r, 2.0 * (double)npix * c.cin * c.cout, (double)npix * 3.0 * c.cout * sz, 0);
+        if (r) { r->kind = 1; r->B = 1; r->H = 1; r->W = (int)npix; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.n_fast; }
         check(launch_conv(dtype, MODE_GEMM1, c.nt, a, s), "mix launch");
         prof_end(r);
     }
@@ -565,6 +572,7 @@ struct Runner {
         pick_order(a, c, (double)B * H * W * c.cp0 * sz);
         ProfRec* r;
         prof_begin(r, 2.0 * (double)npix * 4.0 * c.cin * c.cout, ((double)B * H * W * c.cin + (double)npix * c.cout) * sz, 0);
+        if (r) { r->kind = 2; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.n_fast; }
         check(launch_conv(dtype, MODE_GEMM1, c.nt, a, s), "crush launch");
         prof_end(r);
     }
@@ -828,6 +836,25 @@ extern "C" int mz_profile_enable(mz_handle* h, int on) {
     if (!h) return fail(MZ_ERR_INVALID_ARGUMENT, "null handle");
     h->prof = on != 0;
     h->recs_used = 0;
+    return MZ_OK;
+}
+
+extern "C" int mz_profile_dump(mz_handle* h, const char* path) {
+    // One CSV row per profiled launch since the last reset (does not reset).
+    if (!h || !path) return fail(MZ_ERR_INVALID_ARGUMENT, "null argument");
+    FILE* f = fopen(path, "w");
+    if (!f) return fail(MZ_ERR_INVALID_ARGUMENT, "cannot open %s", path);
+    fprintf(f, "kind,B,H,W,cin,cout,nt,ntiles,mtiles,n_fast,ms,gflop,tflops,alg_GBps\n");
+    for (size_t i = 0; i < h->recs_used; ++i) {
+        ProfRec& r = h->recs[i];
+        if (hipEventSynchronize(r.b) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+        const char* kn = r.kind == 0 ? "conv3" : (r.kind == 1 ? "mix" : "crush");
+        fprintf(f, "%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.3f,%.1f,%.1f\n", kn, r.B, r.H, r.W, r.cin, r.cout, r.nt, r.ntiles,
+                r.mtiles, r.n_fast, ms, r.flops / 1e9, r.flops / (ms * 1e-3) / 1e12, r.bytes / (ms * 1e-3) / 1e9);
+    }
+    fclose(f);
     return MZ_OK;
 }
 

@@ -38,7 +38,8 @@ struct ConvArgs {
     int B, H, W;       // input grid
     int Ho, Wo;        // output pixel grid of the GEMM (== H,W for CONV3; H/2,W/2 for CRUSH)
     int cp0, cp1;      // padded channels of in0 / in1
-    int nchunks;       // K chunks in total
+    int nchunks;       // K chunks in total (GEMM1: padded to a multiple of 3 with zero weights)
+    int nchunks_real;  // chunks that exist in the sources
     int nchunks0;      // CONCAT: chunks that come from in0; CRUSH: chunks per tap
     int src;           // SrcKind
     int ntiles;        // N tiles (of 32*NT channels)
@@ -54,8 +55,6 @@ struct ConvArgs {
     int Hi, Wi;        // FINAL: img size
     int clamp;
     int use_glds;      // stage through global_load_lds (1) or through registers (0)
-    float bic_w[8][4]; // bicubic phase weights
-    int bic_f[8];      // bicubic phase base offsets (-1 or 0)
 };
 
 size_t conv_lds_bytes(int mode, int nt);

@@ -25,6 +25,7 @@ namespace mz {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct TF32 {
     static constexpr int SZ = 4;
@@ -97,21 +98,24 @@ template <> __device__ __forceinline__ void ld4<TF16>(const void* p, float v[4])
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
 
 // ---- one K-chunk of matrix work: acc[n][pixel] += W[n][k] * X[pixel][k] ------------------------
-template <class TT> __device__ __forceinline__ void mma(f32x16& acc, const uint4& w, const uint4& x);
-template <> __device__ __forceinline__ void mma<TBF16>(f32x16& acc, const uint4& w, const uint4& x) {
+template <class TT> __device__ __forceinline__ void mma(f32x16& acc, const u32x4& w, const u32x4& x);
+template <> __device__ __forceinline__ void mma<TBF16>(f32x16& acc, const u32x4& w, const u32x4& x) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x),
                                                   acc, 0, 0, 0);
 }
-template <> __device__ __forceinline__ void mma<TF16>(f32x16& acc, const uint4& w, const uint4& x) {
+template <> __device__ __forceinline__ void mma<TF16>(f32x16& acc, const u32x4& w, const u32x4& x) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, w), __builtin_bit_cast(f16x8_t, x),
                                                  acc, 0, 0, 0);
 }
 // f32: lane half h holds channels 4h..4h+3 of the 8-channel chunk; step e contracts {e, 4+e}.
-template <> __device__ __forceinline__ void mma<TF32>(f32x16& acc, const uint4& w, const uint4& x) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, w.x), __builtin_bit_cast(float, x.x), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, w.y), __builtin_bit_cast(float, x.y), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, w.z), __builtin_bit_cast(float, x.z), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, w.w), __builtin_bit_cast(float, x.w), acc, 0, 0, 0);
+template <> __device__ __forceinline__ void mma<TF32>(f32x16& acc, const u32x4& w, const u32x4& x) {
+    // (bit_cast of the whole vector: __builtin_bit_cast on a single ext-vector element reads element 0)
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 wf = __builtin_bit_cast(f32x4, w), xf = __builtin_bit_cast(f32x4, x);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[0], xf[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[1], xf[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[2], xf[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[3], xf[3], acc, 0, 0, 0);
 }
 
 // LDS-DMA: 64 lanes x 16 bytes, per-lane global source, wave-uniform LDS destination.
@@ -133,6 +137,36 @@ __device__ __forceinline__ void cubic_coeffs(float t, float c[4]) {
     c[3] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
 }
 
+// ---- LDS fragment reads hidden from hipcc's waitcnt pass ----------------------------------------
+// hipcc makes every ds_read it can see wait for ALL pending LDS-DMA (s_waitcnt vmcnt(0)), which would
+// serialise the prefetch of the next K-stage behind the current stage's first fragment read.  The
+// fragment reads of the main loop are therefore inline asm: the DMA -> read ordering is enforced by
+// hand (s_waitcnt vmcnt(0) + barrier at the end of each stage) and the read -> MFMA ordering by the
+// `wait_frags` statement, which names every destination as "+v" so no MFMA can be scheduled above it.
+// Only lgkmcnt(0) is used, so compiler-generated scalar loads in flight cannot confuse the count.
+template <int OFF> __device__ __forceinline__ u32x4 lds_read128(uint32_t addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset is 16 bits");
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+
+template <int NT> struct Frags {
+    u32x4 x0, x1;
+    u32x4 w[NT];
+};
+template <int NT> __device__ __forceinline__ void wait_frags(Frags<NT>& f) {
+    if constexpr (NT == 1)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.x0), "+v"(f.x1), "+v"(f.w[0])::"memory");
+    else if constexpr (NT == 2)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.x0), "+v"(f.x1), "+v"(f.w[0]), "+v"(f.w[1])::"memory");
+    else if constexpr (NT == 3)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.x0), "+v"(f.x1), "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2])::"memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(f.x0), "+v"(f.x1), "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3])::"memory");
+}
+
 // ================================================================================================
 // implicit-GEMM convolution
 // ================================================================================================
@@ -151,6 +185,41 @@ template <> struct Geo<MODE_GEMM1> {
     static constexpr int PLANE = 256 * 16;
     static constexpr int MF_STRIDE = 32 * 16;
 };
+
+
+// One "item" = one (chunk-in-stage, filter tap) pair = one 32-byte K-chunk of matrix work.
+template <int NT, int MODE, int ITEM> __device__ __forceinline__ void issue_reads(Frags<NT>& f, uint32_t a_addr, uint32_t b_addr) {
+    using G = Geo<MODE>;
+    constexpr int s = ITEM / G::TAPS, tap = ITEM % G::TAPS;
+    constexpr int aofs = (MODE == MODE_CONV3) ? ((tap / 3) * 34 + (tap % 3)) * 16 : s * 8192;
+    f.x0 = lds_read128<aofs>(a_addr);
+    f.x1 = lds_read128<aofs + G::MF_STRIDE>(a_addr);
+    f.w[0] = lds_read128<(ITEM * NT + 0) * 1024>(b_addr);
+    if constexpr (NT > 1) f.w[1] = lds_read128<(ITEM * NT + 1) * 1024>(b_addr);
+    if constexpr (NT > 2) f.w[2] = lds_read128<(ITEM * NT + 2) * 1024>(b_addr);
+    if constexpr (NT > 3) f.w[3] = lds_read128<(ITEM * NT + 3) * 1024>(b_addr);
+}
+template <class TT, int NT> __device__ __forceinline__ void mma_item(f32x16 (&acc)[2][NT], const Frags<NT>& f) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        mma<TT>(acc[0][nt], f.w[nt], f.x0);
+        mma<TT>(acc[1][nt], f.w[nt], f.x1);
+    }
+}
+// cur holds the (already waited-for) fragments of ITEM; nxt receives those of ITEM+1 while ITEM's MFMAs run.
+template <class TT, int NT, int MODE, int ITEM, int NITEMS>
+__device__ __forceinline__ void run_items(f32x16 (&acc)[2][NT], Frags<NT>& cur, Frags<NT>& nxt, uint32_t a_addr,
+                                          uint32_t b_addr) {
+    if constexpr (ITEM < NITEMS) {
+        if constexpr (ITEM + 1 < NITEMS) issue_reads<NT, MODE, ITEM + 1>(nxt, a_addr, b_addr);
+        // keep the next item's LDS reads ahead of this item's MFMAs: their latency hides under the matrix work
+        __builtin_amdgcn_sched_barrier(0);
+        mma_item<TT, NT>(acc, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ITEM + 1 < NITEMS) wait_frags<NT>(nxt);
+        run_items<TT, NT, MODE, ITEM + 1, NITEMS>(acc, nxt, cur, a_addr, b_addr);
+    }
+}
 
 template <class TT, int NT, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
@@ -240,11 +309,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
         char* Bbuf = Abuf + A_BYTES;
         // ---- weights: contiguous run of pieces, one KiB per wave-instruction ----
         const int kc0 = st * S;
-        int npieces = B_PIECES;
-        if (MODE == MODE_GEMM1) {
-            const int left = a.nchunks - kc0;
-            if (left < S) npieces = left * NT;
-        }
+        const int npieces = B_PIECES;  // GEMM1: nchunks is padded to a multiple of S with zero weights
         const char* wsrc = wtile + (size_t)kc0 * (TAPS * NT * 1024);
         for (int j = w; j < npieces; j += 4) {
             if (a.use_glds) {
@@ -270,9 +335,10 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 const int kc = kc0 + s;
-                if (kc >= a.nchunks) break;
                 const char* base;
-                if (a.src == SRC_CRUSH) {
+                if (kc >= a.nchunks_real) {
+                    base = nullptr;  // K padding: zero activations against zero weights
+                } else if (a.src == SRC_CRUSH) {
                     const int tap = kc / a.nchunks0;
                     const int cc = kc - tap * a.nchunks0;
                     const long long toff = ((long long)(tap >> 1) * a.W + (tap & 1)) * a.cp0 * SZ + cc * 32;
@@ -307,6 +373,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
     const int a_lane = (MODE == MODE_CONV3) ? h * G::PLANE + ((2 * w) * 34 + r) * 16
                                             : h * G::PLANE + (64 * w + r) * 16;
 
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const int nstages = (a.nchunks + S - 1) / S;
     stage_load(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -316,30 +383,12 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
         const int cur = st & 1;
         if (st + 1 < nstages) stage_load(st + 1, cur ^ 1);
 
-        const char* Ab = smem + cur * STAGE + a_lane;
-        const char* Bb = smem + cur * STAGE + A_BYTES + lane * 16;
-        int s_eff = S;
-        if (MODE == MODE_GEMM1) {
-            const int left = a.nchunks - st * S;
-            s_eff = left < S ? left : S;
-        }
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            if (s < s_eff) {
-#pragma unroll
-                for (int tap = 0; tap < TAPS; ++tap) {
-                    const int aofs = (MODE == MODE_CONV3) ? ((tap / 3) * 34 + (tap % 3)) * 16 : s * 8192;
-                    const uint4 xa = *(const uint4*)(Ab + aofs);
-                    const uint4 xb = *(const uint4*)(Ab + aofs + G::MF_STRIDE);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const uint4 wv = *(const uint4*)(Bb + ((s * TAPS + tap) * NT + nt) * 1024);
-                        mma<TT>(acc[0][nt], wv, xa);
-                        mma<TT>(acc[1][nt], wv, xb);
-                    }
-                }
-            }
-        }
+        const uint32_t a_addr = lds_base + cur * STAGE + a_lane;
+        const uint32_t b_addr = lds_base + cur * STAGE + A_BYTES + lane * 16;
+        Frags<NT> fa, fb;
+        issue_reads<NT, MODE, 0>(fa, a_addr, b_addr);
+        wait_frags<NT>(fa);
+        run_items<TT, NT, MODE, 0, TAPS * S>(acc, fa, fb, a_addr, b_addr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -352,6 +401,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
             char* ep = smem + w * (32 * ROWF);
             const long long plane_i = (long long)a.Hi * a.Wi;
             const long long plane_o = (long long)a.Hout * a.Wout;
+#pragma unroll
             for (int mf = 0; mf < 2; ++mf) {
                 const int y = y0 + 2 * w + mf;
 #pragma unroll
@@ -416,6 +466,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
     constexpr int EPU = 16 / SZ;       // channels per unit
     char* ep = smem + w * (32 * ROWB);
 
+#pragma unroll
     for (int mf = 0; mf < 2; ++mf) {
         // pixel owned by this lane in the accumulator layout
         long long pix_acc = -1;  // linear pixel index in the (B,Ho,Wo) grid
@@ -599,7 +650,7 @@ template <class TT> __global__ void pack_kernel(const PackArgs a, long long tota
         const int cpt = a.cp0 / CK;  // chunks per tap
         const int st = kc / cpt;
         const int k = (kc - st * cpt) * CK + kin;
-        ci = k < a.c0 ? k : -1;
+        ci = (st < 4 && k < a.c0) ? k : -1;  // st >= 4: K padding
         ty = st >> 1;
         tx = st & 1;
     }
