@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-launches", default="", help="write a per-launch CSV (shape, ms, TFLOP/s) of the profiled step")
     ap.add_argument("--no-gather", action="store_true", help="skip the output gather in the timed step (N > 1)")
+    ap.add_argument("--images-per-gpu", type=int, default=0, help="override the workload's batch (profiling runs only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -142,6 +143,9 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     model_name, per_gpu, H, W, desc = WORKLOADS[args.workload]
+    if args.images_per_gpu > 0:
+        per_gpu = args.images_per_gpu
+        desc += f" [batch overridden to {per_gpu}: profiling run, not a benchmark result]"
     cfg = MODELS[model_name]
     dtype = DTYPES[args.dtype]
     r = cfg["upscale_ratio"]

@@ -68,21 +68,6 @@ def test_golden_low_precision(name, dtype):
     assert err <= gate["max_abs"] and p >= gate["psnr"] and qa_err <= gate["qa"]
 
 
-def test_staging_paths_agree_bit_for_bit():
-    """LDS-DMA (global_load_lds) staging and register staging must produce identical bits."""
-    case = GoldenCase("g2_odd_37x45")
-    x = case.image().to("cuda", torch.bfloat16)
-    outs = []
-    for flag in ("1", "0"):
-        os.environ["MZ_USE_GLDS"] = flag
-        try:
-            m = build(case, case.weights(), torch.bfloat16)
-            outs.append(m.forward(x)[0])
-        finally:
-            os.environ.pop("MZ_USE_GLDS", None)
-    assert torch.equal(outs[0], outs[1])
-
-
 def test_batch_independence_and_micro_batching():
     case = GoldenCase("g9_4x_c32")
     m = build(case, case.weights(), torch.bfloat16)

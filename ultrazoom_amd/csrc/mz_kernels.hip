@@ -170,6 +170,13 @@ template <int NT> __device__ __forceinline__ void wait_frags(Frags<NT>& f) {
 // ================================================================================================
 // implicit-GEMM convolution
 // ================================================================================================
+// Staging goes through LDS-DMA (global_load_lds).  -DMZ_REG_STAGING builds the same kernels with plain
+// global loads + ds_write instead (a debugging aid: both variants must produce identical bits).
+#ifdef MZ_REG_STAGING
+static constexpr bool kGlds = false;
+#else
+static constexpr bool kGlds = true;
+#endif
 template <int MODE> struct Geo;
 template <> struct Geo<MODE_CONV3> {
     static constexpr int TAPS = 9;
@@ -187,23 +194,42 @@ template <> struct Geo<MODE_GEMM1> {
 };
 
 
-// One "item" = one (chunk-in-stage, filter tap) pair = one 32-byte K-chunk of matrix work.
-template <int NT, int MODE, int ITEM> __device__ __forceinline__ void issue_reads(Frags<NT>& f, uint32_t a_addr, uint32_t b_addr) {
+// One "item" = one (chunk-in-stage, filter tap) pair = one 32-byte K-chunk of matrix work:
+// 2 + NT fragment reads (two pixel fragments, NT weight fragments) feeding 2 * NT MFMAs.
+template <int NT, int MODE, int ITEM, int K> __device__ __forceinline__ void issue_read(Frags<NT>& f, uint32_t a_addr, uint32_t b_addr) {
     using G = Geo<MODE>;
     constexpr int s = ITEM / G::TAPS, tap = ITEM % G::TAPS;
     constexpr int aofs = (MODE == MODE_CONV3) ? ((tap / 3) * 34 + (tap % 3)) * 16 : s * 8192;
-    f.x0 = lds_read128<aofs>(a_addr);
-    f.x1 = lds_read128<aofs + G::MF_STRIDE>(a_addr);
-    f.w[0] = lds_read128<(ITEM * NT + 0) * 1024>(b_addr);
-    if constexpr (NT > 1) f.w[1] = lds_read128<(ITEM * NT + 1) * 1024>(b_addr);
-    if constexpr (NT > 2) f.w[2] = lds_read128<(ITEM * NT + 2) * 1024>(b_addr);
-    if constexpr (NT > 3) f.w[3] = lds_read128<(ITEM * NT + 3) * 1024>(b_addr);
+    if constexpr (K == 0) f.x0 = lds_read128<aofs>(a_addr);
+    else if constexpr (K == 1) f.x1 = lds_read128<aofs + G::MF_STRIDE>(a_addr);
+    else if constexpr (K < 2 + NT) f.w[K - 2] = lds_read128<(ITEM * NT + (K - 2)) * 1024>(b_addr);
 }
-template <class TT, int NT> __device__ __forceinline__ void mma_item(f32x16 (&acc)[2][NT], const Frags<NT>& f) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        mma<TT>(acc[0][nt], f.w[nt], f.x0);
-        mma<TT>(acc[1][nt], f.w[nt], f.x1);
+template <int NT, int MODE, int ITEM> __device__ __forceinline__ void issue_reads(Frags<NT>& f, uint32_t a_addr, uint32_t b_addr) {
+    issue_read<NT, MODE, ITEM, 0>(f, a_addr, b_addr);
+    issue_read<NT, MODE, ITEM, 1>(f, a_addr, b_addr);
+    issue_read<NT, MODE, ITEM, 2>(f, a_addr, b_addr);
+    issue_read<NT, MODE, ITEM, 3>(f, a_addr, b_addr);
+    issue_read<NT, MODE, ITEM, 4>(f, a_addr, b_addr);
+    issue_read<NT, MODE, ITEM, 5>(f, a_addr, b_addr);
+}
+// MFMA step M of an item (M = 2*nt + mf), followed by two of the NEXT item's fragment reads: the reads issue in
+// the shadow of the MFMA just issued (the matrix pipe accepts one 32x32x16 MFMA per 32 cycles), and all of them
+// are in flight at least (2*NT - 3) MFMAs before the item's closing s_waitcnt.
+template <class TT, int NT, int MODE, int ITEM, int NITEMS, int M>
+__device__ __forceinline__ void mfma_steps(f32x16 (&acc)[2][NT], const Frags<NT>& cur, Frags<NT>& nxt, uint32_t a_addr,
+                                           uint32_t b_addr) {
+    if constexpr (M < 2 * NT) {
+        mma<TT>(acc[M & 1][M >> 1], cur.w[M >> 1], (M & 1) ? cur.x1 : cur.x0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ITEM + 1 < NITEMS) {
+            issue_read<NT, MODE, ITEM + 1, 2 * M>(nxt, a_addr, b_addr);
+            issue_read<NT, MODE, ITEM + 1, 2 * M + 1>(nxt, a_addr, b_addr);
+            if constexpr (M == 2 * NT - 1) {  // NT == 1: 3 reads, 2 MFMAs
+                issue_read<NT, MODE, ITEM + 1, 2 * M + 2>(nxt, a_addr, b_addr);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mfma_steps<TT, NT, MODE, ITEM, NITEMS, M + 1>(acc, cur, nxt, a_addr, b_addr);
     }
 }
 // cur holds the (already waited-for) fragments of ITEM; nxt receives those of ITEM+1 while ITEM's MFMAs run.
@@ -211,11 +237,8 @@ template <class TT, int NT, int MODE, int ITEM, int NITEMS>
 __device__ __forceinline__ void run_items(f32x16 (&acc)[2][NT], Frags<NT>& cur, Frags<NT>& nxt, uint32_t a_addr,
                                           uint32_t b_addr) {
     if constexpr (ITEM < NITEMS) {
-        if constexpr (ITEM + 1 < NITEMS) issue_reads<NT, MODE, ITEM + 1>(nxt, a_addr, b_addr);
-        // keep the next item's LDS reads ahead of this item's MFMAs: their latency hides under the matrix work
         __builtin_amdgcn_sched_barrier(0);
-        mma_item<TT, NT>(acc, cur);
-        __builtin_amdgcn_sched_barrier(0);
+        mfma_steps<TT, NT, MODE, ITEM, NITEMS, 0>(acc, cur, nxt, a_addr, b_addr);
         if constexpr (ITEM + 1 < NITEMS) wait_frags<NT>(nxt);
         run_items<TT, NT, MODE, ITEM + 1, NITEMS>(acc, nxt, cur, a_addr, b_addr);
     }
@@ -312,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
         const int npieces = B_PIECES;  // GEMM1: nchunks is padded to a multiple of S with zero weights
         const char* wsrc = wtile + (size_t)kc0 * (TAPS * NT * 1024);
         for (int j = w; j < npieces; j += 4) {
-            if (a.use_glds) {
+            if (kGlds) {
                 glds16(wsrc + j * 1024 + lane * 16, Bbuf + j * 1024);
             } else {
                 *(uint4*)(Bbuf + j * 1024 + lane * 16) = *(const uint4*)(wsrc + j * 1024 + lane * 16);
@@ -325,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
             for (int i = 0; i < 3; ++i) {
                 if (i == 2 && w == 3) break;  // entries 704.. do not exist
                 const char* src = aoff[i] >= 0 ? (const char*)a.in0 + aoff[i] + kbyte : (const char*)a.zero;
-                if (a.use_glds) {
+                if (kGlds) {
                     glds16(src, Abuf + (64 * w + 256 * i) * 16);
                 } else {
                     *(uint4*)(Abuf + (tid + 256 * i) * 16) = *(const uint4*)src;
@@ -352,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
                 for (int hh = 0; hh < 2; ++hh) {
                     const char* src = base ? base + hh * 16 : (const char*)a.zero;
                     char* dstw = Abuf + s * 8192 + hh * 4096 + (64 * w) * 16;
-                    if (a.use_glds) {
+                    if (kGlds) {
                         glds16(src, dstw);
                     } else {
                         *(uint4*)(dstw + lane * 16) = *(const uint4*)src;
