@@ -106,7 +106,7 @@ int mz_forward(mz_handle* h, const void* x, void* out_sr, float* out_qa, int B, 
 
 /* ---- single operators, exported for the parity tests (tests/test_ops_gpu.py) ---------------
  * These run the SAME kernels mz_forward launches, on caller-provided tensors.
- * Activation tensors here are the library's internal layout: NHWC with the channel count padded
+ * Activation tensors here are the library's internal layout: plane-major [B][P][H][W][16 bytes], channel count padded
  * to a multiple of 16, element type = dtype.  mz_padded_channels(c) gives that count. */
 int mz_padded_channels(int c);
 

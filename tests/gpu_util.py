@@ -1,4 +1,4 @@
-"""Helpers for the GPU parity tests: layout conversion to/from the library's NHWC padded tensors."""
+"""Helpers for the GPU parity tests: layout conversion to/from the library's plane-major activation tensors."""
 
 from __future__ import annotations
 
@@ -18,16 +18,35 @@ def pad16(c: int) -> int:
     return (c + 15) // 16 * 16
 
 
-def to_nhwc(x: torch.Tensor, dtype, garbage_pad: bool = False) -> torch.Tensor:
-    """[B,C,H,W] float CPU -> [B,H,W,pad16(C)] dtype on the GPU (pad channels zero)."""
+def planes_per(dtype) -> int:
+    """Channels per 16-byte plane."""
+    return 16 // torch.empty((), dtype=dtype).element_size()
+
+
+def alloc_act(B: int, C: int, H: int, W: int, dtype, fill: float = 7.0) -> torch.Tensor:
+    """An activation tensor in the library's layout [B, P, H, W, channels-per-plane], pre-filled with garbage."""
+    ppu = planes_per(dtype)
+    return torch.full((B, pad16(C) // ppu, H, W, ppu), fill, dtype=dtype, device="cuda")
+
+
+def to_act(x: torch.Tensor, dtype) -> torch.Tensor:
+    """[B,C,H,W] float CPU -> plane-major [B, P, H, W, ppu] `dtype` on the GPU (pad channels zero)."""
     B, C, H, W = x.shape
-    t = torch.zeros(B, H, W, pad16(C), dtype=dtype, device="cuda")
-    t[..., :C] = x.permute(0, 2, 3, 1).to(dtype)
-    return t.contiguous()
+    ppu = planes_per(dtype)
+    t = torch.zeros(B, pad16(C), H, W, dtype=dtype, device="cuda")
+    t[:, :C] = x.to(dtype)
+    return t.reshape(B, pad16(C) // ppu, ppu, H, W).permute(0, 1, 3, 4, 2).contiguous()
 
 
-def from_nhwc(t: torch.Tensor, C: int) -> torch.Tensor:
-    return t[..., :C].permute(0, 3, 1, 2).float().cpu()
+def from_act(t: torch.Tensor, C: int) -> torch.Tensor:
+    B, P, H, W, ppu = t.shape
+    return t.permute(0, 1, 4, 2, 3).reshape(B, P * ppu, H, W)[:, :C].float().cpu()
+
+
+def pad_part(t: torch.Tensor, C: int) -> torch.Tensor:
+    """The pad channels (>= C) of an activation tensor; the kernels must write zeros there."""
+    B, P, H, W, ppu = t.shape
+    return t.permute(0, 1, 4, 2, 3).reshape(B, P * ppu, H, W)[:, C:]
 
 
 def q(x: torch.Tensor, dtype) -> torch.Tensor:

@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from gpu_util import DTYPES, OP_TOL, from_nhwc, op_conv, pad16, q, stream_ptr, to_nhwc
+from gpu_util import DTYPES, OP_TOL, alloc_act, from_act, op_conv, pad16, pad_part, q, stream_ptr, to_act
 from oracle import mewzoom_oracle as oracle
 from ultrazoom_amd import _ffi
 from ultrazoom_amd.synth import hash_uniform
@@ -48,16 +48,16 @@ def test_conv3x3(dt, case):
     B, H, W, cin, cout, silu = case
     x = q(rnd((B, cin, H, W), 1), dtype)
     w = q(wrnd((cout, cin, 3, 3), 2), dtype)
-    out = torch.full((B, H, W, pad16(cout)), 7.0, dtype=dtype, device="cuda")
-    op_conv(dtype, 0, to_nhwc(x, dtype), None, w, 0.0, out, B, H, W, cin, cout, silu=silu)
+    out = alloc_act(B, cout, H, W, dtype)
+    op_conv(dtype, 0, to_act(x, dtype), None, w, 0.0, out, B, H, W, cin, cout, silu=silu)
     want = F.conv2d(x, w, padding=1)
     if silu:
         want = F.silu(want)
-    got = from_nhwc(out, cout)
+    got = from_act(out, cout)
     err = (got - want).abs().max().item()
     assert err < OP_TOL[dt], f"max-abs {err}"
     if pad16(cout) > cout:
-        assert out[..., cout:].abs().max().item() == 0.0, "pad channels must be written as zeros"
+        assert pad_part(out, cout).abs().max().item() == 0.0, "pad channels must be written as zeros"
 
 
 D2S_CASES = [
@@ -77,14 +77,14 @@ def test_subpixel_conv(dt, case):
     cq = cout // 4
     x = q(rnd((B, cin, H, W), 3), dtype)
     w = q(wrnd((cout, cin, 3, 3), 4), dtype)
-    out = torch.full((B, Hout, Wout, pad16(cq)), 7.0, dtype=dtype, device="cuda")
-    op_conv(dtype, 1, to_nhwc(x, dtype), None, w, 0.0, out, B, H, W, cin, cout, Hout, Wout)
+    out = alloc_act(B, cq, Hout, Wout, dtype)
+    op_conv(dtype, 1, to_act(x, dtype), None, w, 0.0, out, B, H, W, cin, cout, Hout, Wout)
     want = oracle.fit_to(oracle.subpixel_conv(x, w), (Hout, Wout))
-    got = from_nhwc(out, cq)
+    got = from_act(out, cq)
     err = (got - want).abs().max().item()
     assert err < OP_TOL[dt], f"max-abs {err}"
     if pad16(cq) > cq:
-        assert out[..., cq:].abs().max().item() == 0.0
+        assert pad_part(out, cq).abs().max().item() == 0.0
 
 
 CRUSH_CASES = [(2, 7, 9, 16, 32), (1, 16, 64, 48, 96), (1, 21, 19, 24, 40), (1, 34, 66, 96, 192), (1, 9, 40, 192, 384)]
@@ -97,10 +97,10 @@ def test_pixel_crush(dt, case):
     B, H, W, cin, cout = case
     x = q(rnd((B, cin, H, W), 5), dtype)
     w = q(wrnd((cout, cin, 2, 2), 6), dtype)
-    out = torch.full((B, H // 2, W // 2, pad16(cout)), 7.0, dtype=dtype, device="cuda")
-    op_conv(dtype, 2, to_nhwc(x, dtype), None, w, 0.0, out, B, H, W, cin, cout)
+    out = alloc_act(B, cout, H // 2, W // 2, dtype)
+    op_conv(dtype, 2, to_act(x, dtype), None, w, 0.0, out, B, H, W, cin, cout)
     want = F.conv2d(x, w, stride=2)
-    err = (from_nhwc(out, cout) - want).abs().max().item()
+    err = (from_act(out, cout) - want).abs().max().item()
     assert err < OP_TOL[dt], f"max-abs {err}"
 
 
@@ -116,13 +116,13 @@ def test_adaptive_residual_mix(dt, case):
     z = q(rnd((B, c, H, W), 8), dtype)
     w = q(wrnd((c, 2 * c, 1, 1), 9), dtype)
     alpha = 0.37
-    out = torch.full((B, H, W, pad16(c)), 7.0, dtype=dtype, device="cuda")
-    op_conv(dtype, 3, to_nhwc(x, dtype), to_nhwc(z, dtype), w, alpha, out, B, H, W, 2 * c, c)
+    out = alloc_act(B, c, H, W, dtype)
+    op_conv(dtype, 3, to_act(x, dtype), to_act(z, dtype), w, alpha, out, B, H, W, 2 * c, c)
     want = oracle.residual_mix(x, z, w, torch.tensor(alpha))
-    err = (from_nhwc(out, c) - want).abs().max().item()
+    err = (from_act(out, c) - want).abs().max().item()
     assert err < OP_TOL[dt], f"max-abs {err}"
     if pad16(c) > c:
-        assert out[..., c:].abs().max().item() == 0.0
+        assert pad_part(out, c).abs().max().item() == 0.0
 
 
 @pytest.mark.parametrize("dt", list(DTYPES))
@@ -133,17 +133,17 @@ def test_stem(dt, case):
     x = q(rnd((B, 3, H, W), 10).abs(), dtype)
     w = rnd((c, 3, 1, 1), 11)
     b = rnd((c,), 12, 0.1)
-    out = torch.full((B, H, W, pad16(c)), 7.0, dtype=dtype, device="cuda")
+    out = alloc_act(B, c, H, W, dtype)
     xd, wd, bd = x.to("cuda", dtype).contiguous(), w.cuda(), b.cuda()
     _ffi.check(_ffi.lib().mz_op_stem(
         _ffi.dtype_code(dtype), ctypes.c_void_p(xd.data_ptr()), ctypes.c_void_p(wd.data_ptr()),
         ctypes.c_void_p(bd.data_ptr()), ctypes.c_void_p(out.data_ptr()), B, H, W, c, ctypes.c_void_p(stream_ptr())))
     torch.cuda.synchronize()
     want = F.conv2d(x, w, b)
-    err = (from_nhwc(out, c) - want).abs().max().item()
+    err = (from_act(out, c) - want).abs().max().item()
     assert err < OP_TOL[dt], f"max-abs {err}"
     if pad16(c) > c:
-        assert out[..., c:].abs().max().item() == 0.0
+        assert pad_part(out, c).abs().max().item() == 0.0
 
 
 FINAL_CASES = [
@@ -167,7 +167,7 @@ def test_final_subpixel_bicubic_add_clamp(dt, case):
     img = q(rnd((B, 3, Hi, Wi), 14).abs(), dtype)
     w = q(wrnd((12, cin, 3, 3), 15) * 0.5, dtype)
     out = torch.full((B, 3, 2 * H, 2 * W), 7.0, dtype=dtype, device="cuda")
-    fd, imd, wd = to_nhwc(feat, dtype), img.to("cuda", dtype).contiguous(), w.cuda()
+    fd, imd, wd = to_act(feat, dtype), img.to("cuda", dtype).contiguous(), w.cuda()
     _ffi.check(_ffi.lib().mz_op_final(
         _ffi.dtype_code(dtype), ctypes.c_void_p(fd.data_ptr()), ctypes.c_void_p(imd.data_ptr()),
         ctypes.c_void_p(wd.data_ptr()), ctypes.c_void_p(out.data_ptr()), B, H, W, cin, R, clamp,

@@ -507,12 +507,13 @@ struct Runner {
         if (zero_override) a.zero = zero_override;
         a.in0 = in; a.out = out;
         a.B = B; a.H = H; a.W = W; a.Ho = H; a.Wo = W;
-        a.cp0 = c.cp0;
+        a.p0 = c.cp0 * dtype_size(dtype) / 16;
         a.src = SRC_PLAIN;
         a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 7) / 8;
         a.mtiles = B * a.tiles_x * a.tiles_y;
         a.epi = epi; a.silu = silu;
         a.cp_out = epi == EPI_D2S ? c.cq_p : pad16(c.cout);
+        a.p_out = a.cp_out * dtype_size(dtype) / 16;
         a.Hout = Hout; a.Wout = Wout;
         a.img = img; a.R = R; a.clamp = clamp;
         if (epi == EPI_FINAL) { a.Hi = Hout / R; a.Wi = Wout / R; }
@@ -527,28 +528,26 @@ struct Runner {
     }
 
     // AdaptiveResidualMix (model.py:826-839): out = x + sigmoid(alpha)*sigmoid(W[x;z])*(z - x)
-    void mix(const ConvW& c, float alpha, const void* x, const void* z, void* out, long long npix,
-             const void* zero_override = nullptr) {
+    void mix(const ConvW& c, float alpha, const void* x, const void* z, void* out, int B, int H, int W) {
         if (rc) return;
         ConvArgs a;
         base_args(a, c);
-        if (zero_override) a.zero = zero_override;
         a.in0 = x; a.in1 = z; a.out = out;
-        a.B = 1; a.H = 1; a.W = 1; a.Ho = 1; a.Wo = (int)npix;
-        a.B = 1; a.Ho = 1;
-        // linear pixel grid: B*Ho*Wo = npix
-        a.cp0 = c.cp0; a.cp1 = pad16(c.c1);
+        a.B = B; a.H = H; a.W = W; a.Ho = H; a.Wo = W;
+        const int sz = dtype_size(dtype);
+        a.p0 = c.cp0 * sz / 16; a.p1 = pad16(c.c1) * sz / 16;
         a.nchunks0 = c.cp0 / chunk_channels(dtype);
         a.src = SRC_CONCAT;
+        const long long npix = (long long)B * H * W;
         a.mtiles = (int)((npix + 255) / 256);
         a.epi = EPI_MIX;
         a.cp_out = pad16(c.cout);
+        a.p_out = a.cp_out * sz / 16;
         a.mix_scale = 1.0f / (1.0f + std::exp(-alpha));
-        const double sz = dtype_size(dtype);
-        pick_order(a, c, (double)npix * (a.cp0 + a.cp1) * sz);
+        pick_order(a, c, (double)npix * (c.cp0 + pad16(c.c1)) * sz);
         ProfRec* r;
         prof_begin(r, 2.0 * (double)npix * c.cin * c.cout, (double)npix * 3.0 * c.cout * sz, 0);
-        if (r) { r->kind = 1; r->B = 1; r->H = 1; r->W = (int)npix; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.n_fast; }
+        if (r) { r->kind = 1; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.n_fast; }
         check(launch_conv(dtype, MODE_GEMM1, c.nt, a, s), "mix launch");
         prof_end(r);
     }
@@ -561,13 +560,14 @@ struct Runner {
         if (zero_override) a.zero = zero_override;
         a.in0 = in; a.out = out;
         a.B = B; a.H = H; a.W = W; a.Ho = H / 2; a.Wo = W / 2;
-        a.cp0 = c.cp0;
+        a.p0 = c.cp0 * dtype_size(dtype) / 16;
         a.nchunks0 = c.cp0 / chunk_channels(dtype);
         a.src = SRC_CRUSH;
         const long long npix = (long long)B * a.Ho * a.Wo;
         a.mtiles = (int)((npix + 255) / 256);
         a.epi = EPI_STORE;
         a.cp_out = pad16(c.cout);
+        a.p_out = a.cp_out * dtype_size(dtype) / 16;
         const double sz = dtype_size(dtype);
         pick_order(a, c, (double)B * H * W * c.cp0 * sz);
         ProfRec* r;
@@ -592,7 +592,7 @@ static int forward_micro(mz_handle* h, const char* x, char* out_sr, float* out_q
         // EncoderBlock / DecoderBlock (model.py:507-511): conv1 -> SiLU -> conv2 -> adaptive mix with the input
         run.conv3(b.conv1, xin, hid, nb, hh, ww, EPI_STORE, 1, 0, 0);
         run.conv3(b.conv2, hid, z, nb, hh, ww, EPI_STORE, 0, 0, 0);
-        run.mix(b.mix, b.alpha, xin, z, yout, (long long)nb * hh * ww);
+        run.mix(b.mix, b.alpha, xin, z, yout, nb, hh, ww);
     };
 
     // stem (model.py:158): NCHW image -> NHWC features
@@ -646,7 +646,7 @@ static int forward_micro(mz_handle* h, const char* x, char* out_sr, float* out_q
             // pick a level-l buffer that is not the saved encoder feature
             slot = (feat_slot[l] + 1) % 3;
             char* dst = ws + p.R[l][slot];
-            run.mix(h->skipmix[d - 1], h->skip_alpha[d - 1], feat[l], u, dst, (long long)nb * p.hs[l] * p.ws[l]);
+            run.mix(h->skipmix[d - 1], h->skip_alpha[d - 1], feat[l], u, dst, nb, p.hs[l], p.ws[l]);
             cur = dst;
         }
         for (auto& b : h->dec_blocks[d]) {
@@ -757,7 +757,7 @@ extern "C" int mz_op_conv(int dtype, int kind, const void* in0, const void* in1,
             }
             break;
         case 2: run.crush(c, in0, out, B, H, W); break;
-        case 3: run.mix(c, alpha, in0, in1, out, (long long)B * H * W); break;
+        case 3: run.mix(c, alpha, in0, in1, out, B, H, W); break;
     }
     fake.zero_page = nullptr;
     HIPCHK(hipStreamSynchronize(s));

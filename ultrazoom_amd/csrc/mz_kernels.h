@@ -37,7 +37,8 @@ struct ConvArgs {
     const void* img;   // EPI_FINAL: NCHW low-resolution image
     int B, H, W;       // input grid
     int Ho, Wo;        // output pixel grid of the GEMM (== H,W for CONV3; H/2,W/2 for CRUSH)
-    int cp0, cp1;      // padded channels of in0 / in1
+    int p0, p1;        // planes (16-byte channel groups) of in0 / in1: padded_channels * sizeof / 16
+    int p_out;         // planes of the output tensor (D2S: of the shuffled target)
     int nchunks;       // K chunks in total (GEMM1: padded to a multiple of 3 with zero weights)
     int nchunks_real;  // chunks that exist in the sources
     int nchunks0;      // CONCAT: chunks that come from in0; CRUSH: chunks per tap

@@ -10,6 +10,11 @@
 // (reg&3) + 8*(reg>>2) + 4*(lane>>5), the column = lane&31 = pixel): NHWC packing in the epilogue
 // needs no cross-lane traffic.
 //
+// Activation tensors in HBM are "plane-major": [B][P][H][W][16 bytes], a plane being 16 bytes of
+// consecutive channels (8 bf16/f16 or 4 f32 channels); P = padded_channels * sizeof / 16.  A 3x3 halo
+// row or a run of pixels of one plane is then CONTIGUOUS in memory, so a global_load_lds instruction
+// touches a handful of cache lines instead of one per lane.
+//
 // LDS image of one K-stage (all sizes in bytes; a "chunk" is 32 bytes of channels per pixel, i.e.
 // 16 bf16/f16 channels or 8 f32 channels, split in two 16-byte "planes" = the two lane halves):
 //   A (activations)  CONV3: [plane 2][pixel 352 (10 rows x 34 cols halo, padded)][16]   = 11264
@@ -177,6 +182,11 @@ static constexpr bool kGlds = false;
 #else
 static constexpr bool kGlds = true;
 #endif
+// -DMZ_ABLATE=<mask> builds timing-only variants (WRONG results) used to price the parts of the main loop:
+//   1 no LDS-DMA staging inside the loop, 2 no vmcnt/barrier at the end of a stage, 4 no fragment reads.
+#ifndef MZ_ABLATE
+#define MZ_ABLATE 0
+#endif
 template <int MODE> struct Geo;
 template <> struct Geo<MODE_CONV3> {
     static constexpr int TAPS = 9;
@@ -221,7 +231,7 @@ __device__ __forceinline__ void mfma_steps(f32x16 (&acc)[2][NT], const Frags<NT>
     if constexpr (M < 2 * NT) {
         mma<TT>(acc[M & 1][M >> 1], cur.w[M >> 1], (M & 1) ? cur.x1 : cur.x0);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (ITEM + 1 < NITEMS) {
+        if constexpr (ITEM + 1 < NITEMS && !(MZ_ABLATE & 4)) {
             issue_read<NT, MODE, ITEM + 1, 2 * M>(nxt, a_addr, b_addr);
             issue_read<NT, MODE, ITEM + 1, 2 * M + 1>(nxt, a_addr, b_addr);
             if constexpr (M == 2 * NT - 1) {  // NT == 1: 3 reads, 2 MFMAs
@@ -239,8 +249,11 @@ __device__ __forceinline__ void run_items(f32x16 (&acc)[2][NT], Frags<NT>& cur, 
     if constexpr (ITEM < NITEMS) {
         __builtin_amdgcn_sched_barrier(0);
         mfma_steps<TT, NT, MODE, ITEM, NITEMS, 0>(acc, cur, nxt, a_addr, b_addr);
-        if constexpr (ITEM + 1 < NITEMS) wait_frags<NT>(nxt);
-        run_items<TT, NT, MODE, ITEM + 1, NITEMS>(acc, nxt, cur, a_addr, b_addr);
+        if constexpr (ITEM + 1 < NITEMS && !(MZ_ABLATE & 4)) wait_frags<NT>(nxt);
+        if constexpr (MZ_ABLATE & 4)
+            run_items<TT, NT, MODE, ITEM + 1, NITEMS>(acc, cur, nxt, a_addr, b_addr);
+        else
+            run_items<TT, NT, MODE, ITEM + 1, NITEMS>(acc, nxt, cur, a_addr, b_addr);
     }
 }
 
@@ -308,24 +321,25 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
             const int py = p / 34, px = p - py * 34;
             const int gy = y0 - 1 + py, gx = x0 - 1 + px;
             const bool ok = (e < 704) && (p < 340) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            aoff[i] = ok ? (((long long)b * a.H + gy) * a.W + gx) * a.cp0 * SZ + plane * 16 : -1;
+            aoff[i] = ok ? ((((long long)b * a.p0 + plane) * a.H + gy) * a.W + gx) * 16 : -1;
         }
     } else {
         const long long m = m0 + tid;
         aoff[0] = aoff[1] = aoff[2] = -1;
         if (m < M) {
+            const int hwo = a.Ho * a.Wo;
+            const int bb = (int)(m / hwo);
+            const int pix = (int)(m - (long long)bb * hwo);
             if (a.src == SRC_CRUSH) {
-                const int ox = (int)(m % a.Wo);
-                const long long t = m / a.Wo;
-                const int oy = (int)(t % a.Ho);
-                const long long bb = t / a.Ho;
-                aoff[0] = ((bb * a.H + 2 * oy) * a.W + 2 * ox) * a.cp0 * SZ;
+                const int oy = pix / a.Wo, ox = pix - oy * a.Wo;
+                aoff[0] = ((long long)bb * a.p0 * a.H * a.W + (long long)(2 * oy) * a.W + 2 * ox) * 16;
             } else {
-                aoff[0] = m * a.cp0 * SZ;
-                aoff[1] = m * a.cp1 * SZ;
+                aoff[0] = ((long long)bb * a.p0 * hwo + pix) * 16;
+                aoff[1] = ((long long)bb * a.p1 * hwo + pix) * 16;
             }
         }
     }
+    const long long plane_in = (long long)a.H * a.W * 16;  // bytes between two planes of an input tensor
 
     auto stage_load = [&](int st, int buf) {
         char* Abuf = smem + buf * STAGE;
@@ -335,6 +349,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
         const int npieces = B_PIECES;  // GEMM1: nchunks is padded to a multiple of S with zero weights
         const char* wsrc = wtile + (size_t)kc0 * (TAPS * NT * 1024);
         for (int j = w; j < npieces; j += 4) {
+            if ((MZ_ABLATE & 16) && st > 0) break;  // timing-only: no weight staging inside the loop
             if (kGlds) {
                 glds16(wsrc + j * 1024 + lane * 16, Bbuf + j * 1024);
             } else {
@@ -342,8 +357,9 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
             }
         }
         // ---- activations ----
+        if ((MZ_ABLATE & 8) && st > 0) return;  // timing-only: no activation staging inside the loop
         if (MODE == MODE_CONV3) {
-            const int kbyte = kc0 * 32;
+            const long long kbyte = 2LL * kc0 * plane_in;  // a K-chunk = two planes
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 if (i == 2 && w == 3) break;  // entries 704.. do not exist
@@ -364,16 +380,16 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
                 } else if (a.src == SRC_CRUSH) {
                     const int tap = kc / a.nchunks0;
                     const int cc = kc - tap * a.nchunks0;
-                    const long long toff = ((long long)(tap >> 1) * a.W + (tap & 1)) * a.cp0 * SZ + cc * 32;
+                    const long long toff = ((long long)(tap >> 1) * a.W + (tap & 1)) * 16 + 2LL * cc * plane_in;
                     base = aoff[0] >= 0 ? (const char*)a.in0 + aoff[0] + toff : nullptr;
                 } else if (kc < a.nchunks0) {
-                    base = aoff[0] >= 0 ? (const char*)a.in0 + aoff[0] + kc * 32 : nullptr;
+                    base = aoff[0] >= 0 ? (const char*)a.in0 + aoff[0] + 2LL * kc * plane_in : nullptr;
                 } else {
-                    base = aoff[1] >= 0 ? (const char*)a.in1 + aoff[1] + (kc - a.nchunks0) * 32 : nullptr;
+                    base = aoff[1] >= 0 ? (const char*)a.in1 + aoff[1] + 2LL * (kc - a.nchunks0) * plane_in : nullptr;
                 }
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
-                    const char* src = base ? base + hh * 16 : (const char*)a.zero;
+                    const char* src = base ? base + hh * plane_in : (const char*)a.zero;
                     char* dstw = Abuf + s * 8192 + hh * 4096 + (64 * w) * 16;
                     if (kGlds) {
                         glds16(src, dstw);
@@ -404,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
 
     for (int st = 0; st < nstages; ++st) {
         const int cur = st & 1;
-        if (st + 1 < nstages) stage_load(st + 1, cur ^ 1);
+        if (st + 1 < nstages && !(MZ_ABLATE & 1)) stage_load(st + 1, cur ^ 1);
 
         const uint32_t a_addr = lds_base + cur * STAGE + a_lane;
         const uint32_t b_addr = lds_base + cur * STAGE + A_BYTES + lane * 16;
@@ -412,8 +428,10 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
         issue_reads<NT, MODE, 0>(fa, a_addr, b_addr);
         wait_frags<NT>(fa);
         run_items<TT, NT, MODE, 0, TAPS * S>(acc, fa, fb, a_addr, b_addr);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (!(MZ_ABLATE & 2)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     }
 
     // ============================== epilogue ==============================
@@ -486,19 +504,29 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
     constexpr int ROWB = BN * SZ + 16;
     constexpr int UPP = BN * SZ / 16;  // 16-byte units per pixel row
     constexpr int UPW = UPP / 2;       // units per lane (32 pixels * UPP / 64 lanes)
-    constexpr int EPU = 16 / SZ;       // channels per unit
     char* ep = smem + w * (32 * ROWB);
 
+    constexpr int PPU = SZ == 2 ? 8 : 4;  // channels per plane (= per 16-byte unit)
+    const long long hwo = (long long)a.Ho * a.Wo;
 #pragma unroll
     for (int mf = 0; mf < 2; ++mf) {
-        // pixel owned by this lane in the accumulator layout
-        long long pix_acc = -1;  // linear pixel index in the (B,Ho,Wo) grid
+        // Pixel of this lane: the accumulator column (lane & 31) and the pixel this lane stores below coincide.
+        int bimg = -1;       // image index, -1 = pixel outside the tensor
+        long long pix = 0;   // y * Wo + x inside the image
+        int py = 0, pxx = 0;
         if (MODE == MODE_CONV3) {
-            const int y = y0 + 2 * w + mf, x = x0 + r;
-            if (y < a.H && x < a.W) pix_acc = ((long long)b * a.H + y) * a.W + x;
+            py = y0 + 2 * w + mf;
+            pxx = x0 + r;
+            if (py < a.H && pxx < a.W) {
+                bimg = b;
+                pix = (long long)py * a.W + pxx;
+            }
         } else {
             const long long m = m0 + 64 * w + 32 * mf + r;
-            if (m < M) pix_acc = m;
+            if (m < M) {
+                bimg = (int)(m / hwo);
+                pix = m - (long long)bimg * hwo;
+            }
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -515,9 +543,10 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
                 if (a.epi == EPI_MIX) {
                     float xv[4] = {0.f, 0.f, 0.f, 0.f}, zv[4] = {0.f, 0.f, 0.f, 0.f};
                     const int n = nbase + nloc;
-                    if (pix_acc >= 0 && n < a.cp_out) {
-                        ld4<TT>((const char*)a.in0 + (pix_acc * a.cp0 + n) * SZ, xv);
-                        ld4<TT>((const char*)a.in1 + (pix_acc * a.cp1 + n) * SZ, zv);
+                    if (bimg >= 0 && n < a.cp_out) {
+                        const int plane = n / PPU, inner = (n - plane * PPU) * SZ;
+                        ld4<TT>((const char*)a.in0 + (((long long)bimg * a.p0 + plane) * hwo + pix) * 16 + inner, xv);
+                        ld4<TT>((const char*)a.in1 + (((long long)bimg * a.p1 + plane) * hwo + pix) * 16 + inner, zv);
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = xv[j] + a.mix_scale * sigmoidf_(v[j]) * (zv[j] - xv[j]);
@@ -526,30 +555,23 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
             }
         }
         __syncthreads();
+        // read back: lane -> pixel (lane & 31) of planes (lane >> 5) + 2 i: 32 consecutive pixels of one plane are
+        // 512 contiguous bytes in HBM
 #pragma unroll
         for (int i = 0; i < UPW; ++i) {
-            const int u = lane + 64 * i;
-            const int px = u / UPP;
-            const int cu = u - px * UPP;
-            const uint4 val = *(const uint4*)(ep + px * ROWB + cu * 16);
-            const int n = nbase + cu * EPU;
-            if (MODE == MODE_CONV3) {
-                const int y = y0 + 2 * w + mf, x = x0 + px;
-                if (y < a.H && x < a.W) {
-                    if (a.epi == EPI_D2S) {
-                        if (n < 4 * a.cp_out) {
-                            const int ij = n / a.cp_out;
-                            const int c = n - ij * a.cp_out;
-                            const int Y = 2 * y + (ij >> 1), X = 2 * x + (ij & 1);
-                            *(uint4*)((char*)a.out + ((((long long)b * a.Hout + Y) * a.Wout + X) * a.cp_out + c) * SZ) = val;
-                        }
-                    } else if (n < a.cp_out) {
-                        *(uint4*)((char*)a.out + ((((long long)b * a.H + y) * a.W + x) * a.cp_out + n) * SZ) = val;
-                    }
+            const int cu = h + 2 * i;
+            const uint4 val = *(const uint4*)(ep + r * ROWB + cu * 16);
+            const int n = nbase + cu * PPU;
+            if (bimg < 0) continue;
+            if (MODE == MODE_CONV3 && a.epi == EPI_D2S) {
+                if (n < 4 * a.cp_out) {
+                    const int ij = n / a.cp_out;
+                    const int c = n - ij * a.cp_out;
+                    const int Y = 2 * py + (ij >> 1), X = 2 * pxx + (ij & 1);
+                    *(uint4*)((char*)a.out + ((((long long)b * a.p_out + c / PPU) * a.Hout + Y) * a.Wout + X) * 16) = val;
                 }
-            } else {
-                const long long m = m0 + 64 * w + 32 * mf + px;
-                if (m < M && n < a.cp_out) *(uint4*)((char*)a.out + (m * a.cp_out + n) * SZ) = val;
+            } else if (n < a.cp_out) {
+                *(uint4*)((char*)a.out + (((long long)bimg * a.p_out + n / PPU) * hwo + pix) * 16) = val;
             }
         }
         __syncthreads();
@@ -720,16 +742,17 @@ hipError_t launch_pack_stem(const float* w, const float* b, float* dst, int c, i
     return hipGetLastError();
 }
 
-// FanOutProjection (reference model.py:239-242): per-pixel 3 -> C affine, NCHW image -> NHWC features.
-template <class TT> __global__ void stem_kernel(const void* x, const float4* w4, void* out, long long npix, long long HW,
-                                                int cp) {
+// FanOutProjection (reference model.py:239-242): per-pixel 3 -> C affine, NCHW image -> plane-major features.
+template <class TT> __global__ void stem_kernel(const void* x, const float4* w4, void* out, long long total, long long HW,
+                                                int groups) {
     constexpr int SZ = TT::SZ;
-    const int groups = cp / 8;
+    constexpr int NPL = SZ / 2;  // planes per group of 8 channels
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= npix * groups) return;
-    const long long pix = idx / groups;
-    const int g = (int)(idx - pix * groups);
-    const long long b = pix / HW, p = pix - b * HW;
+    if (idx >= total) return;
+    const long long p = idx % HW;  // pixel fastest: loads and stores are contiguous along p
+    const long long t = idx / HW;
+    const int g = (int)(t % groups);
+    const long long b = t / groups;
     const char* xp = (const char*)x + (b * 3 * HW + p) * SZ;
     const float r0 = ld1<TT>(xp), r1 = ld1<TT>(xp + HW * SZ), r2 = ld1<TT>(xp + 2 * HW * SZ);
     float v[8];
@@ -738,36 +761,40 @@ template <class TT> __global__ void stem_kernel(const void* x, const float4* w4,
         const float4 wv = w4[g * 8 + j];
         v[j] = wv.w + wv.x * r0 + wv.y * r1 + wv.z * r2;
     }
-    char* op = (char*)out + (pix * cp + g * 8) * SZ;
-    st4<TT>(op, v);
-    st4<TT>(op + 4 * SZ, v + 4);
+    char* op = (char*)out + ((b * groups * NPL + (long long)g * NPL) * HW + p) * 16;
+    if (SZ == 2) {
+        st4<TT>(op, v);
+        st4<TT>(op + 4 * SZ, v + 4);
+    } else {
+        st4<TT>(op, v);
+        st4<TT>(op + HW * 16, v + 4);
+    }
 }
 hipError_t launch_stem(int dtype, const void* x, const float* w4, void* out, int B, int H, int W, int cp, hipStream_t s) {
-    const long long HW = (long long)H * W, npix = HW * B;
-    const long long total = npix * (cp / 8);
+    const long long HW = (long long)H * W;
+    const int groups = cp / 8;
+    const long long total = HW * B * groups;
     const int blocks = (int)((total + 255) / 256);
     switch (dtype) {
-        case DT_F32: hipLaunchKernelGGL(stem_kernel<TF32>, dim3(blocks), dim3(256), 0, s, x, (const float4*)w4, out, npix, HW, cp); break;
-        case DT_BF16: hipLaunchKernelGGL(stem_kernel<TBF16>, dim3(blocks), dim3(256), 0, s, x, (const float4*)w4, out, npix, HW, cp); break;
-        case DT_F16: hipLaunchKernelGGL(stem_kernel<TF16>, dim3(blocks), dim3(256), 0, s, x, (const float4*)w4, out, npix, HW, cp); break;
+        case DT_F32: hipLaunchKernelGGL(stem_kernel<TF32>, dim3(blocks), dim3(256), 0, s, x, (const float4*)w4, out, total, HW, groups); break;
+        case DT_BF16: hipLaunchKernelGGL(stem_kernel<TBF16>, dim3(blocks), dim3(256), 0, s, x, (const float4*)w4, out, total, HW, groups); break;
+        case DT_F16: hipLaunchKernelGGL(stem_kernel<TF16>, dim3(blocks), dim3(256), 0, s, x, (const float4*)w4, out, total, HW, groups); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
 // Decoder.crop_feature_maps zero padding (reference model.py:667-673, 681-687): bottom rows / right columns.
-__global__ void zero_border_kernel(char* t, int B, int Hout, int Wout, int rowbytes16, int Hv, int Wv) {
-    // one thread per 16-byte unit of a border pixel; border pixels: rows >= Hv (all columns) and cols >= Wv (rows < Hv)
+__global__ void zero_border_kernel(char* t, int B, int Hout, int Wout, int planes, int Hv, int Wv) {
+    // one thread per border pixel of one plane; border = rows >= Hv (all columns) and columns >= Wv (rows < Hv)
     const long long nb_rows = (long long)(Hout - Hv) * Wout;
     const long long nb_cols = (long long)Hv * (Wout - Wv);
-    const long long per_img = nb_rows + nb_cols;
+    const long long per_plane = nb_rows + nb_cols;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = per_img * B * rowbytes16;
+    const long long total = per_plane * B * planes;
     if (idx >= total) return;
-    const int u = (int)(idx % rowbytes16);
-    long long pb = idx / rowbytes16;
-    const long long b = pb / per_img;
-    long long k = pb - b * per_img;
+    long long k = idx % per_plane;
+    const long long bp = idx / per_plane;  // b * planes + plane
     int y, x;
     if (k < nb_rows) {
         y = Hv + (int)(k / Wout);
@@ -778,16 +805,16 @@ __global__ void zero_border_kernel(char* t, int B, int Hout, int Wout, int rowby
         y = (int)(k / wc);
         x = Wv + (int)(k % wc);
     }
-    *(uint4*)(t + ((((long long)b * Hout + y) * Wout + x) * rowbytes16 + u) * 16) = make_uint4(0, 0, 0, 0);
+    *(uint4*)(t + ((bp * Hout + y) * Wout + x) * 16) = make_uint4(0, 0, 0, 0);
 }
 hipError_t launch_zero_border(int dtype, void* t, int B, int Hout, int Wout, int cp, int Hv, int Wv, hipStream_t s) {
     if (Hv >= Hout && Wv >= Wout) return hipSuccess;
-    const int rb16 = cp * dtype_size(dtype) / 16;
-    const long long per_img = (long long)(Hout - Hv) * Wout + (long long)Hv * (Wout - Wv);
-    const long long total = per_img * B * rb16;
+    const int planes = cp * dtype_size(dtype) / 16;
+    const long long per_plane = (long long)(Hout - Hv) * Wout + (long long)Hv * (Wout - Wv);
+    const long long total = per_plane * B * planes;
     if (total <= 0) return hipSuccess;
     hipLaunchKernelGGL(zero_border_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (char*)t, B, Hout, Wout,
-                       rb16, Hv, Wv);
+                       planes, Hv, Wv);
     return hipGetLastError();
 }
 
@@ -795,10 +822,12 @@ hipError_t launch_zero_border(int dtype, void* t, int B, int Hout, int Wout, int
 template <class TT> __global__ void qa_reduce_kernel(const void* feat, const float* bias, float* qa, int P, int cp, int F) {
     constexpr int SZ = TT::SZ;
     __shared__ float red[256];
+    constexpr int PPU = 16 / SZ;  // channels per plane
     const int b = blockIdx.x, f = blockIdx.y;
-    const char* base = (const char*)feat + ((long long)b * P * cp + f) * SZ;
+    const int planes = cp / PPU;
+    const char* base = (const char*)feat + (((long long)b * planes + f / PPU) * P) * 16 + (f % PPU) * SZ;
     float sum = 0.0f;
-    for (int p = threadIdx.x; p < P; p += 256) sum += ld1<TT>(base + (long long)p * cp * SZ);
+    for (int p = threadIdx.x; p < P; p += 256) sum += ld1<TT>(base + (long long)p * 16);
     red[threadIdx.x] = sum;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
