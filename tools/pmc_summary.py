@@ -9,8 +9,8 @@ for f in glob.glob(os.path.join(root, "*", "*", "*_counter_collection.csv")):
     seen = set()
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        if "conv_kernel" not in name: continue
-        short = name.split("conv_kernel<")[1].split(">")[0].replace("mz::", "")
+        if "conv_kernel" not in name and "conv3w_kernel" not in name: continue
+        short = ("W:" if "conv3w" in name else "") + name.split("_kernel<")[1].split(">")[0].replace("mz::", "")
         key = (short, int(r["Grid_Size"]) // 256)
         data[key][r["Counter_Name"]] += float(r["Counter_Value"])
         did = (f, r["Dispatch_Id"])

@@ -452,11 +452,31 @@ extern "C" int mz_workspace_bytes(const mz_handle* h, int B, int H, int W, int m
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
+// Diagnostic stamp buffer (only -DMZ_STAMP kernel builds write to it; MZ_DEBUG_STAMPS=1 allocates it).
+static unsigned long long* debug_buffer() {
+    static unsigned long long* buf = nullptr;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        if (getenv("MZ_DEBUG_STAMPS")) {
+            if (hipMalloc((void**)&buf, 16 * 64 * 8 * sizeof(unsigned long long)) != hipSuccess) buf = nullptr;
+            else (void)hipMemset(buf, 0, 16 * 64 * 8 * sizeof(unsigned long long));
+        }
+    }
+    return buf;
+}
+extern "C" int mz_debug_read(unsigned long long* host_dst) {
+    unsigned long long* b = debug_buffer();
+    if (!b) return -1;
+    return hipMemcpy(host_dst, b, 16 * 64 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -6;
+}
+
 struct Runner {
     mz_handle* h;
     hipStream_t s;
     int dtype;
     int rc = MZ_OK;
+    bool wide_tiles = getenv("MZ_NO_WIDE") == nullptr;  // MZ_NO_WIDE=1 forces the 256-pixel kernel (A/B timing)
 
     void prof_begin(ProfRec*& r, double flops, double bytes, int is_conv3) {
         r = nullptr;
@@ -484,6 +504,7 @@ struct Runner {
         memset(&a, 0, sizeof(a));
         a.wpk = c.packed;
         a.zero = h ? h->zero_page : nullptr;
+        a.dbg = debug_buffer();
         a.nchunks = c.nchunks;
         a.nchunks_real = c.nchunks_real;
         a.ntiles = c.ntiles;
@@ -509,7 +530,15 @@ struct Runner {
         a.B = B; a.H = H; a.W = W; a.Ho = H; a.Wo = W;
         a.p0 = c.cp0 * dtype_size(dtype) / 16;
         a.src = SRC_PLAIN;
-        a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 7) / 8;
+        // tile shape: the 512-pixel kernels (NT <= 3) in the shape that wastes fewer padded pixels, else 8 x 32
+        int mode = MODE_CONV3, th = 8, tw = 32;
+        if (c.nt <= 3 && wide_tiles) {
+            const long long waste16 = (long long)((H + 15) / 16 * 16) * ((W + 31) / 32 * 32);
+            const long long waste8 = (long long)((H + 7) / 8 * 8) * ((W + 63) / 64 * 64);
+            if (waste8 <= waste16) { mode = MODE_C3W8; th = 8; tw = 64; }
+            else { mode = MODE_C3W16; th = 16; tw = 32; }
+        }
+        a.tiles_x = (W + tw - 1) / tw; a.tiles_y = (H + th - 1) / th;
         a.mtiles = B * a.tiles_x * a.tiles_y;
         a.epi = epi; a.silu = silu;
         a.cp_out = epi == EPI_D2S ? c.cq_p : pad16(c.cout);
@@ -523,7 +552,7 @@ struct Runner {
         ProfRec* r;
         prof_begin(r, 2.0 * px * 9.0 * c.cin * c.cout, px * (c.cin + c.cout) * sz + 9.0 * c.cin * c.cout * sz, 1);
         if (r) { r->kind = 0; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.n_fast; }
-        check(launch_conv(dtype, MODE_CONV3, c.nt, a, s), "conv3x3 launch");
+        check(launch_conv(dtype, mode, c.nt, a, s), "conv3x3 launch");
         prof_end(r);
     }
 

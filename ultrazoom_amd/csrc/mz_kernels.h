@@ -19,7 +19,8 @@ inline int pad16(int c) { return (c + 15) / 16 * 16; }
 //   MODE_GEMM1 : 1x1 over a gathered K axis; pixel tile = 256 consecutive output pixels
 //                (row-major over B*Ho*Wo).  Sources: SRC_CONCAT ([in0 ; in1] along channels, the
 //                AdaptiveResidualMix gate) or SRC_CRUSH (2x2 stride-2 patch of in0 = PixelCrush).
-enum ConvMode : int { MODE_CONV3 = 0, MODE_GEMM1 = 1 };
+//   MODE_C3W16 / MODE_C3W8 : 3x3 on a 512-pixel tile (16 x 32 or 8 x 64) with 8 compute waves + 1 loader wave
+enum ConvMode : int { MODE_CONV3 = 0, MODE_GEMM1 = 1, MODE_C3W16 = 2, MODE_C3W8 = 3 };
 enum SrcKind : int { SRC_PLAIN = 0, SRC_CONCAT = 1, SRC_CRUSH = 2 };
 enum Epilogue : int {
     EPI_STORE = 0,  // NHWC store (optional SiLU)
@@ -56,6 +57,7 @@ struct ConvArgs {
     int Hi, Wi;        // FINAL: img size
     int clamp;
     int use_glds;      // stage through global_load_lds (1) or through registers (0)
+    unsigned long long* dbg;  // -DMZ_STAMP diagnostic builds: per-stage s_memtime stamps of one workgroup
 };
 
 size_t conv_lds_bytes(int mode, int nt);

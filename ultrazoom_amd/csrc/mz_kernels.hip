@@ -188,9 +188,10 @@ static constexpr bool kGlds = true;
 #define MZ_ABLATE 0
 #endif
 template <int MODE> struct Geo;
-template <> struct Geo<MODE_CONV3> {
+template <> struct Geo<MODE_CONV3> {  // 4 waves, 8 x 32 pixels
     static constexpr int TAPS = 9;
     static constexpr int S = 1;            // chunks per stage
+    static constexpr int ROWW = 34;        // halo row width
     static constexpr int A_ENT = 704;      // 16-byte entries per A image (2 planes x 352)
     static constexpr int PLANE = 352 * 16;
     static constexpr int MF_STRIDE = 34 * 16;  // second M fragment = next tile row
@@ -198,18 +199,42 @@ template <> struct Geo<MODE_CONV3> {
 template <> struct Geo<MODE_GEMM1> {
     static constexpr int TAPS = 1;
     static constexpr int S = 3;
+    static constexpr int ROWW = 0;
     static constexpr int A_ENT = 3 * 512;
     static constexpr int PLANE = 256 * 16;
     static constexpr int MF_STRIDE = 32 * 16;
 };
-
+template <> struct Geo<MODE_C3W16> {  // 8 compute waves, 16 x 32 pixels: wave w owns rows 2w, 2w+1
+    static constexpr int TAPS = 9;
+    static constexpr int S = 1;
+    static constexpr int TH = 16, TW = 32;
+    static constexpr int ROWW = 34;
+    static constexpr int NPIX = 18 * 34;   // 612 halo pixels
+    static constexpr int PLANE_ENT = 640;  // padded so that 2 planes = a whole number of 64-entry DMA instructions
+    static constexpr int A_ENT = 2 * PLANE_ENT;
+    static constexpr int PLANE = PLANE_ENT * 16;
+    static constexpr int MF_STRIDE = 34 * 16;
+    static constexpr int ROW_PER_WAVE = 2;
+};
+template <> struct Geo<MODE_C3W8> {  // 8 compute waves, 8 x 64 pixels: wave w owns row w, fragments = its two halves
+    static constexpr int TAPS = 9;
+    static constexpr int S = 1;
+    static constexpr int TH = 8, TW = 64;
+    static constexpr int ROWW = 66;
+    static constexpr int NPIX = 10 * 66;   // 660 halo pixels
+    static constexpr int PLANE_ENT = 672;
+    static constexpr int A_ENT = 2 * PLANE_ENT;
+    static constexpr int PLANE = PLANE_ENT * 16;
+    static constexpr int MF_STRIDE = 32 * 16;
+    static constexpr int ROW_PER_WAVE = 1;
+};
 
 // One "item" = one (chunk-in-stage, filter tap) pair = one 32-byte K-chunk of matrix work:
 // 2 + NT fragment reads (two pixel fragments, NT weight fragments) feeding 2 * NT MFMAs.
 template <int NT, int MODE, int ITEM, int K> __device__ __forceinline__ void issue_read(Frags<NT>& f, uint32_t a_addr, uint32_t b_addr) {
     using G = Geo<MODE>;
     constexpr int s = ITEM / G::TAPS, tap = ITEM % G::TAPS;
-    constexpr int aofs = (MODE == MODE_CONV3) ? ((tap / 3) * 34 + (tap % 3)) * 16 : s * 8192;
+    constexpr int aofs = (MODE != MODE_GEMM1) ? ((tap / 3) * G::ROWW + (tap % 3)) * 16 : s * 8192;
     if constexpr (K == 0) f.x0 = lds_read128<aofs>(a_addr);
     else if constexpr (K == 1) f.x1 = lds_read128<aofs + G::MF_STRIDE>(a_addr);
     else if constexpr (K < 2 + NT) f.w[K - 2] = lds_read128<(ITEM * NT + (K - 2)) * 1024>(b_addr);
@@ -254,6 +279,375 @@ __device__ __forceinline__ void run_items(f32x16 (&acc)[2][NT], Frags<NT>& cur, 
             run_items<TT, NT, MODE, ITEM + 1, NITEMS>(acc, cur, nxt, a_addr, b_addr);
         else
             run_items<TT, NT, MODE, ITEM + 1, NITEMS>(acc, nxt, cur, a_addr, b_addr);
+    }
+}
+
+// ================================================================================================
+// epilogue, shared by every convolution kernel.  Wave-local: each wave transposes its own 64-pixel x BN tile
+// through its own LDS region `ep`, so no workgroup barrier is needed (LDS operations of one wave execute in
+// program order).  Pixel geometry of the wave's two M fragments:
+//   IS_CONV: fragment mf covers pixels (ey[mf], ex[mf] + r) of image b;   else: linear pixels em[mf] + r.
+// ================================================================================================
+template <class TT, int NT, bool IS_CONV>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2][NT], char* ep, int lane, int nbase, int b,
+                                              const int (&ey)[2], const int (&ex)[2], const long long (&em)[2]) {
+    constexpr int SZ = TT::SZ;
+    constexpr int BN = 32 * NT;
+    const int h = lane >> 5, r = lane & 31;
+    if (a.epi == EPI_FINAL) {
+        if (IS_CONV) {
+            constexpr int ROWF = 80;  // 16 floats + 16 bytes pad
+            const long long plane_i = (long long)a.Hi * a.Wi;
+            const long long plane_o = (long long)a.Hout * a.Wout;
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) {
+                const int y = ey[mf];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[mf][0][4 * q + j];
+                    *(float4*)(ep + r * ROWF + (8 * q + 4 * h) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+                __builtin_amdgcn_wave_barrier();
+                const int px = lane >> 1, jj = lane & 1;
+                const int x = ex[mf] + px;
+                const int X = 2 * x + jj;
+                if (y < a.H && x < a.W) {
+                    // horizontal taps of this output column
+                    const int R = a.R;
+                    const int kx = X / R, phx = X - kx * R;
+                    const float sx = (phx + 0.5f) / (float)R - 0.5f;
+                    const int fx = sx < 0.0f ? -1 : 0;
+                    float cx[4];
+                    cubic_coeffs(sx - (float)fx, cx);
+                    int colx[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) colx[i] = min(max(kx + fx - 1 + i, 0), a.Wi - 1);
+#pragma unroll
+                    for (int i2 = 0; i2 < 2; ++i2) {
+                        const int Y = 2 * y + i2;
+                        const int ky = Y / R, phy = Y - ky * R;
+                        const float sy = (phy + 0.5f) / (float)R - 0.5f;
+                        const int fy = sy < 0.0f ? -1 : 0;
+                        float cy[4];
+                        cubic_coeffs(sy - (float)fy, cy);
+                        int rowy[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) rowy[i] = min(max(ky + fy - 1 + i, 0), a.Hi - 1);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const char* ip = (const char*)a.img + ((long long)b * 3 + c) * plane_i * SZ;
+                            float sres = 0.0f;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const char* rp = ip + (long long)rowy[i] * a.Wi * SZ;
+                                const float rowv = ld1<TT>(rp + colx[0] * SZ) * cx[0] + ld1<TT>(rp + colx[1] * SZ) * cx[1] +
+                                                   ld1<TT>(rp + colx[2] * SZ) * cx[2] + ld1<TT>(rp + colx[3] * SZ) * cx[3];
+                                sres += rowv * cy[i];
+                            }
+                            float v = sres + *(const float*)(ep + px * ROWF + ((2 * i2 + jj) * 4 + c) * 4);
+                            if (a.clamp) v = fminf(fmaxf(v, 0.0f), 1.0f);
+                            st1<TT>((char*)a.out + ((((long long)b * 3 + c) * plane_o) + (long long)Y * a.Wout + X) * SZ, v);
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        return;
+    }
+
+    constexpr int ROWB = BN * SZ + 16;
+    constexpr int UPP = BN * SZ / 16;  // 16-byte units per pixel row
+    constexpr int UPW = UPP / 2;       // units per lane (32 pixels * UPP / 64 lanes)
+    constexpr int PPU = SZ == 2 ? 8 : 4;  // channels per plane (= per 16-byte unit)
+    const long long hwo = (long long)a.Ho * a.Wo;
+    const long long M = (long long)a.B * hwo;
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+        // Pixel of this lane: the accumulator column (lane & 31) and the pixel this lane stores below coincide.
+        int bimg = -1;       // image index, -1 = pixel outside the tensor
+        long long pix = 0;   // y * Wo + x inside the image
+        int py = 0, pxx = 0;
+        if (IS_CONV) {
+            py = ey[mf];
+            pxx = ex[mf] + r;
+            if (py < a.H && pxx < a.W) {
+                bimg = b;
+                pix = (long long)py * a.W + pxx;
+            }
+        } else {
+            const long long m = em[mf] + r;
+            if (m < M) {
+                bimg = (int)(m / hwo);
+                pix = m - (long long)bimg * hwo;
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[mf][nt][4 * q + j];
+                const int nloc = 32 * nt + 8 * q + 4 * h;
+                if (a.silu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] * sigmoidf_(v[j]);
+                }
+                if (a.epi == EPI_MIX) {
+                    float xv[4] = {0.f, 0.f, 0.f, 0.f}, zv[4] = {0.f, 0.f, 0.f, 0.f};
+                    const int n = nbase + nloc;
+                    if (bimg >= 0 && n < a.cp_out) {
+                        const int plane = n / PPU, inner = (n - plane * PPU) * SZ;
+                        ld4<TT>((const char*)a.in0 + (((long long)bimg * a.p0 + plane) * hwo + pix) * 16 + inner, xv);
+                        ld4<TT>((const char*)a.in1 + (((long long)bimg * a.p1 + plane) * hwo + pix) * 16 + inner, zv);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = xv[j] + a.mix_scale * sigmoidf_(v[j]) * (zv[j] - xv[j]);
+                }
+                st4<TT>(ep + r * ROWB + nloc * SZ, v);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // read back: lane -> pixel (lane & 31) of planes (lane >> 5) + 2 i: 32 consecutive pixels of one plane are
+        // 512 contiguous bytes in HBM
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) {
+            const int cu = h + 2 * i;
+            const uint4 val = *(const uint4*)(ep + r * ROWB + cu * 16);
+            const int n = nbase + cu * PPU;
+            if (bimg < 0) continue;
+            if (IS_CONV && a.epi == EPI_D2S) {
+                if (n < 4 * a.cp_out) {
+                    const int ij = n / a.cp_out;
+                    const int c = n - ij * a.cp_out;
+                    const int Y = 2 * py + (ij >> 1), X = 2 * pxx + (ij & 1);
+                    *(uint4*)((char*)a.out + ((((long long)b * a.p_out + c / PPU) * a.Hout + Y) * a.Wout + X) * 16) = val;
+                }
+            } else if (n < a.cp_out) {
+                *(uint4*)((char*)a.out + (((long long)bimg * a.p_out + n / PPU) * hwo + pix) * 16) = val;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ================================================================================================
+// 3x3 convolution, wide tile: 512 output pixels x BN channels per workgroup, 8 compute waves + 1 loader wave.
+//   - the weight stage (9 * NT KiB per K-chunk) is fetched ONCE for 512 pixels, by a dedicated wave, so the
+//     compute waves never pay the issue cost of the weight DMA;
+//   - each compute wave issues only its 2-3 activation DMA instructions per stage;
+//   - 3-slot LDS ring, prefetch distance 2 stages, counted s_waitcnt vmcnt(N): the DMA of stage t+2 stays in
+//     flight across the single barrier of stage t.
+// ================================================================================================
+// -DMZ_STAMP: diagnostic build that records where one workgroup's waves spend each stage (never shipped)
+#if defined(MZ_STAMP) && MZ_STAMP >= 2
+#define STAMP(k)                                                                                                  \
+    do {                                                                                                          \
+        if (a.dbg && blockIdx.x == gridDim.x / 2 && st < 64 && lane == 0) {                                        \
+            unsigned long long t_;                                                                                \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                            \
+            a.dbg[((w * 64) + st) * 8 + (k)] = t_;                                                                \
+        }                                                                                                         \
+    } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+#ifndef MZ_NLOAD
+#define MZ_NLOAD 1
+#endif
+#ifndef MZ_LOADER_SLEEP
+#define MZ_LOADER_SLEEP 0
+#endif
+#ifndef MZ_STAGGER
+#define MZ_STAGGER 0
+#endif
+static constexpr int NLOAD = MZ_NLOAD;  // weight-loader waves per workgroup
+
+template <class TT, int NT, int MODE>
+__global__ __launch_bounds__(512 + 64 * NLOAD, 3) void conv3w_kernel(const ConvArgs a) {
+    using G = Geo<MODE>;
+    constexpr int SZ = TT::SZ;
+    constexpr int BN = 32 * NT;
+    constexpr int A_SLOT = G::A_ENT * 16;
+    constexpr int A_INSTR = G::A_ENT / 64;
+    constexpr int B_PIECES = 9 * NT;
+    constexpr int B_SLOT = B_PIECES * 1024;
+    static_assert(B_PIECES < 60, "vmcnt is a 6-bit counter");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7 compute, 8.. = weight loaders
+    const int h = lane >> 5;
+    const int r = lane & 31;
+
+    int mtile, ntile;
+    {
+        const int nblk = a.mtiles * a.ntiles;
+        const int bid = blockIdx.x;
+        const int q = nblk >> 3, rem = nblk & 7, xcd = bid & 7, pos = bid >> 3;
+        const int L = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + pos;
+        if (a.n_fast) {
+            mtile = L / a.ntiles;
+            ntile = L - mtile * a.ntiles;
+        } else {
+            ntile = L / a.mtiles;
+            mtile = L - ntile * a.mtiles;
+        }
+    }
+    const int nbase = ntile * BN;
+    const int nstages = a.nchunks;
+    char* const Bring = smem + 3 * A_SLOT;
+
+    if (w >= 8) {
+        // ------------------------- weight loader waves -------------------------
+        // loader li takes pieces li, li + NLOAD, ... of every stage (a piece = 1 KiB = one DMA instruction)
+        const int li = w - 8;
+        constexpr int MAXP = (B_PIECES + NLOAD - 1) / NLOAD;
+        const int myp = (B_PIECES - li + NLOAD - 1) / NLOAD;  // MAXP or MAXP - 1
+        const char* wsrc = (const char*)a.wpk + (size_t)ntile * a.nchunks * (B_PIECES * 1024) + lane * 16 + li * 1024;
+        auto loadB = [&](int st, int slot) {
+            const char* src = wsrc + (size_t)((MZ_ABLATE & 32) ? 0 : st) * (B_PIECES * 1024);  // 32: always stage 0 (L2-hot)
+            char* dst = Bring + slot * B_SLOT + li * 1024;
+#pragma unroll
+            for (int j = 0; j < MAXP; ++j) {
+                if (j < myp) glds16(src + j * (NLOAD * 1024), dst + j * (NLOAD * 1024));
+                if (MZ_LOADER_SLEEP > 0) __builtin_amdgcn_s_sleep(MZ_LOADER_SLEEP);  // pace the DMA: no burst at stage start
+            }
+        };
+        loadB(0, 0);
+        if (nstages > 1) loadB(1, 1);
+        int slot2 = 2;  // slot of stage st + 2
+        for (int st = 0; st < nstages; ++st) {
+            STAMP(0);
+            if (st + 1 < nstages) {
+                if (myp == MAXP) wait_vmcnt<MAXP>(); else wait_vmcnt<MAXP - 1>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            STAMP(1);
+            __builtin_amdgcn_s_barrier();
+            STAMP(2);
+            if (st + 2 < nstages && !(MZ_ABLATE & 16)) loadB(st + 2, slot2);
+            STAMP(3);
+            slot2 = slot2 == 2 ? 0 : slot2 + 1;
+        }
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
+
+    // ------------------------- compute waves -------------------------
+    const int tpi = a.tiles_x * a.tiles_y;
+    const int b = mtile / tpi;
+    const int trem = mtile - b * tpi;
+    const int tyi = trem / a.tiles_x;
+    const int y0 = tyi * G::TH;
+    const int x0 = (trem - tyi * a.tiles_x) * G::TW;
+
+    // activation DMA: instruction j covers entries [64 j, 64 j + 64) of the halo image; wave w issues j = w, w+8, w+16
+    const long long plane_in = (long long)a.H * a.W * 16;
+    long long aoff[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int e = 64 * (w + 8 * i) + lane;
+        const int plane = e >= G::PLANE_ENT ? 1 : 0;
+        const int p = e - plane * G::PLANE_ENT;
+        const int py = p / G::ROWW, px = p - py * G::ROWW;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        const bool ok = (e < G::A_ENT) && (p < G::NPIX) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        aoff[i] = ok ? ((((long long)b * a.p0 + plane) * a.H + gy) * a.W + gx) * 16 : -1;
+    }
+    const int nA = (A_INSTR - w + 7) / 8;  // 2 or 3 instructions per stage for this wave
+    auto loadA = [&](int st, int slot) {
+        const long long kbyte = (MZ_ABLATE & 64) ? 0 : 2LL * st * plane_in;  // 64: always chunk 0 (cache-hot)
+        char* dst = smem + slot * A_SLOT;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (w + 8 * i >= A_INSTR) break;
+            const char* src = aoff[i] >= 0 ? (const char*)a.in0 + aoff[i] + kbyte : (const char*)a.zero;
+            glds16(src, dst + (w + 8 * i) * 1024);
+        }
+    };
+    loadA(0, 0);
+    if (nstages > 1) loadA(1, 1);
+#ifdef MZ_STAMP
+    if (a.dbg && w == 0 && lane == 0 && (blockIdx.x & 255) == 7) {  // clock probe: shader cycles vs 100 MHz real time
+        unsigned long long t_, r_;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_)::"memory");
+        a.dbg[(15 * 64 + (blockIdx.x >> 8) % 60) * 8 + 0] = t_;
+        a.dbg[(15 * 64 + (blockIdx.x >> 8) % 60) * 8 + 1] = r_;
+    }
+#endif
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mf][nt][i] = 0.0f;
+
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t a_lane = lds_base + h * G::PLANE + ((G::ROW_PER_WAVE * w) * G::ROWW + r) * 16;
+    const uint32_t b_lane = lds_base + 3 * A_SLOT + lane * 16;
+
+    int slot = 0, slot2 = 2;
+    for (int st = 0; st < nstages; ++st) {
+        // my own activation DMA of stage st has landed once at most the newer stage's instructions are pending
+        STAMP(0);
+        if (st + 1 < nstages) {
+            if (nA == 3) wait_vmcnt<3>(); else wait_vmcnt<2>();
+        } else {
+            wait_vmcnt<0>();
+        }
+        STAMP(1);
+        __builtin_amdgcn_s_barrier();  // stage st is complete in LDS; everyone is done reading stage st-1
+        STAMP(2);
+        if (st + 2 < nstages && !(MZ_ABLATE & 8)) loadA(st + 2, slot2);
+        STAMP(3);
+        // Waves w and w+4 share a SIMD and run the same program: without a stagger they hit the LDS together and
+        // then the matrix pipe together, so the two resources are used in turns instead of concurrently.
+        if (MZ_STAGGER > 0 && w >= 4) __builtin_amdgcn_s_sleep(MZ_STAGGER);
+
+        const uint32_t a_addr = a_lane + slot * A_SLOT;
+        const uint32_t b_addr = b_lane + slot * B_SLOT;
+        Frags<NT> fa, fb;
+        issue_reads<NT, MODE, 0>(fa, a_addr, b_addr);
+        wait_frags<NT>(fa);
+        run_items<TT, NT, MODE, 0, 9>(acc, fa, fb, a_addr, b_addr);
+        STAMP(4);
+        slot = slot == 2 ? 0 : slot + 1;
+        slot2 = slot2 == 2 ? 0 : slot2 + 1;
+    }
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // all fragment reads are done: the ring may be reused by the epilogue
+#ifdef MZ_STAMP
+    if (a.dbg && w == 0 && lane == 0 && (blockIdx.x & 255) == 7) {
+        unsigned long long t_, r_;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_)::"memory");
+        a.dbg[(15 * 64 + (blockIdx.x >> 8) % 60) * 8 + 2] = t_;
+        a.dbg[(15 * 64 + (blockIdx.x >> 8) % 60) * 8 + 3] = r_;
+    }
+#endif
+
+    {
+        constexpr int EPW = 32 * (BN * SZ + 16) > 32 * 80 ? 32 * (BN * SZ + 16) : 32 * 80;
+        int ey[2], ex[2];
+        if (G::ROW_PER_WAVE == 2) {
+            ey[0] = y0 + 2 * w; ey[1] = y0 + 2 * w + 1;
+            ex[0] = x0; ex[1] = x0;
+        } else {
+            ey[0] = y0 + w; ey[1] = y0 + w;
+            ex[0] = x0; ex[1] = x0 + 32;
+        }
+        const long long em[2] = {0, 0};
+        conv_epilogue<TT, NT, true>(a, acc, smem + w * EPW, lane, nbase, b, ey, ex, em);
     }
 }
 
@@ -436,149 +830,22 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
 
     // ============================== epilogue ==============================
     // The staging buffers are free now (every wave is past the last barrier, no DMA in flight).
-    if (a.epi == EPI_FINAL) {
-        if (MODE == MODE_CONV3) {
-            constexpr int ROWF = 80;  // 16 floats + 16 bytes pad
-            char* ep = smem + w * (32 * ROWF);
-            const long long plane_i = (long long)a.Hi * a.Wi;
-            const long long plane_o = (long long)a.Hout * a.Wout;
-#pragma unroll
-            for (int mf = 0; mf < 2; ++mf) {
-                const int y = y0 + 2 * w + mf;
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    float v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = acc[mf][0][4 * q + j];
-                    *(float4*)(ep + r * ROWF + (8 * q + 4 * h) * 4) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-                __syncthreads();
-                const int px = lane >> 1, jj = lane & 1;
-                const int x = x0 + px;
-                const int X = 2 * x + jj;
-                if (y < a.H && x < a.W) {
-                    // horizontal taps of this output column
-                    const int R = a.R;
-                    const int kx = X / R, phx = X - kx * R;
-                    const float sx = (phx + 0.5f) / (float)R - 0.5f;
-                    const int fx = sx < 0.0f ? -1 : 0;
-                    float cx[4];
-                    cubic_coeffs(sx - (float)fx, cx);
-                    int colx[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) colx[i] = min(max(kx + fx - 1 + i, 0), a.Wi - 1);
-#pragma unroll
-                    for (int i2 = 0; i2 < 2; ++i2) {
-                        const int Y = 2 * y + i2;
-                        const int ky = Y / R, phy = Y - ky * R;
-                        const float sy = (phy + 0.5f) / (float)R - 0.5f;
-                        const int fy = sy < 0.0f ? -1 : 0;
-                        float cy[4];
-                        cubic_coeffs(sy - (float)fy, cy);
-                        int rowy[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) rowy[i] = min(max(ky + fy - 1 + i, 0), a.Hi - 1);
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            const char* ip = (const char*)a.img + ((long long)b * 3 + c) * plane_i * SZ;
-                            float sres = 0.0f;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const char* rp = ip + (long long)rowy[i] * a.Wi * SZ;
-                                const float rowv = ld1<TT>(rp + colx[0] * SZ) * cx[0] + ld1<TT>(rp + colx[1] * SZ) * cx[1] +
-                                                   ld1<TT>(rp + colx[2] * SZ) * cx[2] + ld1<TT>(rp + colx[3] * SZ) * cx[3];
-                                sres += rowv * cy[i];
-                            }
-                            float v = sres + *(const float*)(ep + px * ROWF + ((2 * i2 + jj) * 4 + c) * 4);
-                            if (a.clamp) v = fminf(fmaxf(v, 0.0f), 1.0f);
-                            st1<TT>((char*)a.out + ((((long long)b * 3 + c) * plane_o) + (long long)Y * a.Wout + X) * SZ, v);
-                        }
-                    }
-                }
-                __syncthreads();
-            }
-        }
-        return;
-    }
-
-    constexpr int ROWB = BN * SZ + 16;
-    constexpr int UPP = BN * SZ / 16;  // 16-byte units per pixel row
-    constexpr int UPW = UPP / 2;       // units per lane (32 pixels * UPP / 64 lanes)
-    char* ep = smem + w * (32 * ROWB);
-
-    constexpr int PPU = SZ == 2 ? 8 : 4;  // channels per plane (= per 16-byte unit)
-    const long long hwo = (long long)a.Ho * a.Wo;
-#pragma unroll
-    for (int mf = 0; mf < 2; ++mf) {
-        // Pixel of this lane: the accumulator column (lane & 31) and the pixel this lane stores below coincide.
-        int bimg = -1;       // image index, -1 = pixel outside the tensor
-        long long pix = 0;   // y * Wo + x inside the image
-        int py = 0, pxx = 0;
-        if (MODE == MODE_CONV3) {
-            py = y0 + 2 * w + mf;
-            pxx = x0 + r;
-            if (py < a.H && pxx < a.W) {
-                bimg = b;
-                pix = (long long)py * a.W + pxx;
-            }
-        } else {
-            const long long m = m0 + 64 * w + 32 * mf + r;
-            if (m < M) {
-                bimg = (int)(m / hwo);
-                pix = m - (long long)bimg * hwo;
-            }
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[mf][nt][4 * q + j];
-                const int nloc = 32 * nt + 8 * q + 4 * h;
-                if (a.silu) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = v[j] * sigmoidf_(v[j]);
-                }
-                if (a.epi == EPI_MIX) {
-                    float xv[4] = {0.f, 0.f, 0.f, 0.f}, zv[4] = {0.f, 0.f, 0.f, 0.f};
-                    const int n = nbase + nloc;
-                    if (bimg >= 0 && n < a.cp_out) {
-                        const int plane = n / PPU, inner = (n - plane * PPU) * SZ;
-                        ld4<TT>((const char*)a.in0 + (((long long)bimg * a.p0 + plane) * hwo + pix) * 16 + inner, xv);
-                        ld4<TT>((const char*)a.in1 + (((long long)bimg * a.p1 + plane) * hwo + pix) * 16 + inner, zv);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = xv[j] + a.mix_scale * sigmoidf_(v[j]) * (zv[j] - xv[j]);
-                }
-                st4<TT>(ep + r * ROWB + nloc * SZ, v);
-            }
-        }
-        __syncthreads();
-        // read back: lane -> pixel (lane & 31) of planes (lane >> 5) + 2 i: 32 consecutive pixels of one plane are
-        // 512 contiguous bytes in HBM
-#pragma unroll
-        for (int i = 0; i < UPW; ++i) {
-            const int cu = h + 2 * i;
-            const uint4 val = *(const uint4*)(ep + r * ROWB + cu * 16);
-            const int n = nbase + cu * PPU;
-            if (bimg < 0) continue;
-            if (MODE == MODE_CONV3 && a.epi == EPI_D2S) {
-                if (n < 4 * a.cp_out) {
-                    const int ij = n / a.cp_out;
-                    const int c = n - ij * a.cp_out;
-                    const int Y = 2 * py + (ij >> 1), X = 2 * pxx + (ij & 1);
-                    *(uint4*)((char*)a.out + ((((long long)b * a.p_out + c / PPU) * a.Hout + Y) * a.Wout + X) * 16) = val;
-                }
-            } else if (n < a.cp_out) {
-                *(uint4*)((char*)a.out + (((long long)bimg * a.p_out + n / PPU) * hwo + pix) * 16) = val;
-            }
-        }
-        __syncthreads();
+    {
+        constexpr int EPW = 32 * (BN * SZ + 16) > 32 * 80 ? 32 * (BN * SZ + 16) : 32 * 80;
+        const int ey[2] = {y0 + 2 * w, y0 + 2 * w + 1};
+        const int ex[2] = {x0, x0};
+        const long long em[2] = {m0 + 64 * w, m0 + 64 * w + 32};
+        conv_epilogue<TT, NT, MODE == MODE_CONV3>(a, acc, smem + w * EPW, lane, nbase, b, ey, ex, em);
     }
 }
 
 size_t conv_lds_bytes(int mode, int nt) {
+    if (mode == MODE_C3W16 || mode == MODE_C3W8) {
+        const int a_slot = (mode == MODE_C3W16 ? 2 * 640 : 2 * 672) * 16;
+        const size_t ring = 3 * (size_t)(a_slot + 9 * nt * 1024);
+        const size_t epi = 8 * 32 * (size_t)(32 * nt * 4 + 16);
+        return ring > epi ? ring : epi;
+    }
     const int taps = mode == MODE_CONV3 ? 9 : 1;
     const int S = mode == MODE_CONV3 ? 1 : 3;
     const int a_bytes = (mode == MODE_CONV3 ? 704 : 3 * 512) * 16;
@@ -604,7 +871,15 @@ int choose_nt(int n_padded) {
 
 template <class TT, int NT, int MODE> static hipError_t launch_one(const ConvArgs& a, hipStream_t s) {
     const size_t lds = conv_lds_bytes(MODE, NT);
-    hipLaunchKernelGGL((conv_kernel<TT, NT, MODE>), dim3(a.mtiles * a.ntiles), dim3(256), lds, s, a);
+    if constexpr (MODE == MODE_C3W16 || MODE == MODE_C3W8) {
+        if constexpr (NT <= 3) {
+            hipLaunchKernelGGL((conv3w_kernel<TT, NT, MODE>), dim3(a.mtiles * a.ntiles), dim3(512 + 64 * NLOAD), lds, s, a);
+        } else {
+            return hipErrorInvalidValue;
+        }
+    } else {
+        hipLaunchKernelGGL((conv_kernel<TT, NT, MODE>), dim3(a.mtiles * a.ntiles), dim3(256), lds, s, a);
+    }
     return hipGetLastError();
 }
 template <class TT, int MODE> static hipError_t launch_nt(int nt, const ConvArgs& a, hipStream_t s) {
@@ -617,7 +892,13 @@ template <class TT, int MODE> static hipError_t launch_nt(int nt, const ConvArgs
     return hipErrorInvalidValue;
 }
 template <class TT> static hipError_t launch_mode(int mode, int nt, const ConvArgs& a, hipStream_t s) {
-    return mode == MODE_CONV3 ? launch_nt<TT, MODE_CONV3>(nt, a, s) : launch_nt<TT, MODE_GEMM1>(nt, a, s);
+    switch (mode) {
+        case MODE_CONV3: return launch_nt<TT, MODE_CONV3>(nt, a, s);
+        case MODE_GEMM1: return launch_nt<TT, MODE_GEMM1>(nt, a, s);
+        case MODE_C3W16: return launch_nt<TT, MODE_C3W16>(nt, a, s);
+        case MODE_C3W8: return launch_nt<TT, MODE_C3W8>(nt, a, s);
+    }
+    return hipErrorInvalidValue;
 }
 hipError_t launch_conv(int dtype, int mode, int nt, const ConvArgs& a, hipStream_t s) {
     if (a.mtiles <= 0 || a.ntiles <= 0) return hipErrorInvalidValue;
@@ -630,8 +911,10 @@ hipError_t launch_conv(int dtype, int mode, int nt, const ConvArgs& a, hipStream
 }
 
 template <class TT, int NT, int MODE> static hipError_t set_lds_one() {
-    return hipFuncSetAttribute((const void*)conv_kernel<TT, NT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)conv_lds_bytes(MODE, NT));
+    const void* fn;
+    if constexpr (MODE == MODE_C3W16 || MODE == MODE_C3W8) fn = (const void*)conv3w_kernel<TT, NT, MODE>;
+    else fn = (const void*)conv_kernel<TT, NT, MODE>;
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_lds_bytes(MODE, NT));
 }
 template <class TT> static hipError_t set_lds_all() {
     hipError_t e;
@@ -639,6 +922,8 @@ template <class TT> static hipError_t set_lds_all() {
     if ((e = set_lds_one<TT, NT, MODE>()) != hipSuccess) return e;
     MZ_SET(1, MODE_CONV3) MZ_SET(2, MODE_CONV3) MZ_SET(3, MODE_CONV3) MZ_SET(4, MODE_CONV3)
     MZ_SET(1, MODE_GEMM1) MZ_SET(2, MODE_GEMM1) MZ_SET(3, MODE_GEMM1) MZ_SET(4, MODE_GEMM1)
+    MZ_SET(1, MODE_C3W16) MZ_SET(2, MODE_C3W16) MZ_SET(3, MODE_C3W16)
+    MZ_SET(1, MODE_C3W8) MZ_SET(2, MODE_C3W8) MZ_SET(3, MODE_C3W8)
 #undef MZ_SET
     return hipSuccess;
 }
