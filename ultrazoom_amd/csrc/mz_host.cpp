@@ -100,6 +100,8 @@ static void plan_conv(ConvW& c, int dtype, int mode, int cout, int cin, int kh, 
 
 struct BlockW {
     ConvW conv1, conv2, mix;
+    ConvW mixf;          // the gate weights once more, packed for the fused conv2 + mix epilogue (SRC_MIXF)
+    bool fused = false;  // conv2 keeps all its output channels in one workgroup (<= 96): the mix runs in its epilogue
     float alpha = 0.f;
     bool alpha_set = false;
 };
@@ -165,6 +167,18 @@ static void add_block(mz_handle* h, BlockW* b, const std::string& prefix, int c)
     plan_conv(b->conv1, h->dtype, MODE_CONV3, hr * c, c, 3, 3, OUT_PLAIN, SRC_PLAIN, 0, 0);      // model.py:742-744
     plan_conv(b->conv2, h->dtype, MODE_CONV3, c, hr * c, 3, 3, OUT_PLAIN, SRC_PLAIN, 0, 0);      // model.py:746-748
     plan_conv(b->mix, h->dtype, MODE_GEMM1, c, 2 * c, 1, 1, OUT_PLAIN, SRC_CONCAT, c, c);        // model.py:805
+    b->fused = b->conv2.ntiles == 1 && b->conv2.nt <= 3;
+    if (b->fused) {
+        ConvW& f = b->mixf;
+        f.cout = c; f.cin = 2 * c; f.kh = f.kw = 1;
+        f.mode = MODE_GEMM1; f.taps = 1;
+        f.nt = b->conv2.nt; f.ntiles = 1;
+        f.out_map = OUT_PLAIN; f.in_map = SRC_MIXF;
+        f.c0 = c; f.cp0 = pad16(c); f.c1 = c;
+        const int zg = h->dtype == DT_F32 ? 4 : 2;
+        f.nchunks = f.nchunks_real = f.cp0 / chunk_channels(h->dtype) + f.nt * zg;
+        f.packed_sz = packed_bytes(1, f.nt, 1, f.nchunks);
+    }
     add_slot(h, prefix + ".convnet.conv1.weight", SK_CONV, {hr * c, c, 3, 3});
     h->slots.back().conv = &b->conv1;
     add_slot(h, prefix + ".convnet.conv2.weight", SK_CONV, {c, hr * c, 3, 3});
@@ -174,6 +188,7 @@ static void add_block(mz_handle* h, BlockW* b, const std::string& prefix, int c)
     h->slots.back().flag = &b->alpha_set;
     add_slot(h, prefix + ".skip.conv.weight", SK_CONV, {c, 2 * c, 1, 1});
     h->slots.back().conv = &b->mix;
+    h->slots.back().block = b;
 }
 
 static int validate(const mz_config& c) {
@@ -277,8 +292,10 @@ static void free_conv(ConvW& c) {
 
 extern "C" int mz_destroy(mz_handle* h) {
     if (!h) return MZ_OK;
-    for (auto& s : h->slots)
+    for (auto& s : h->slots) {
         if (s.kind == SK_CONV && s.conv) free_conv(*s.conv);
+        if (s.kind == SK_CONV && s.block && s.conv == &s.block->mix) free_conv(s.block->mixf);
+    }
     if (h->stem_w4) (void)hipFree(h->stem_w4);
     if (h->qa_bias) (void)hipFree(h->qa_bias);
     if (h->zero_page) (void)hipFree(h->zero_page);
@@ -342,7 +359,12 @@ extern "C" int mz_set_weight(mz_handle* h, const char* name, const float* dev_f3
     if (rc) return rc;
     hipStream_t st = (hipStream_t)hip_stream;
     switch (s.kind) {
-        case SK_CONV: return pack_conv(*s.conv, h->dtype, dev_f32, st);
+        case SK_CONV: {
+            int rc2 = pack_conv(*s.conv, h->dtype, dev_f32, st);
+            if (rc2 == MZ_OK && s.block && s.block->fused && s.conv == &s.block->mix)
+                rc2 = pack_conv(s.block->mixf, h->dtype, dev_f32, st);
+            return rc2;
+        }
         case SK_ALPHA: {
             // sigmoid(alpha) is folded on the host (model.py:833); one 4-byte read at load time.
             float v = 0.f;
@@ -477,6 +499,7 @@ struct Runner {
     int dtype;
     int rc = MZ_OK;
     bool wide_tiles = getenv("MZ_NO_WIDE") == nullptr;  // MZ_NO_WIDE=1 forces the 256-pixel kernel (A/B timing)
+    bool no_fuse = getenv("MZ_NO_FUSE") != nullptr;     // MZ_NO_FUSE=1 keeps conv2 and the mix as two launches
 
     void prof_begin(ProfRec*& r, double flops, double bytes, int is_conv3) {
         r = nullptr;
@@ -521,7 +544,8 @@ struct Runner {
 
     // conv3x3, pad 1 (model.py:742-748, 900-909, 1010). epi: STORE / D2S / FINAL
     void conv3(const ConvW& c, const void* in, void* out, int B, int H, int W, int epi, int silu, int Hout, int Wout,
-               const void* img = nullptr, int R = 0, int clamp = 0, const void* zero_override = nullptr) {
+               const void* img = nullptr, int R = 0, int clamp = 0, const void* zero_override = nullptr,
+               const ConvW* mixf = nullptr, const void* xin = nullptr, float alpha = 0.f) {
         if (rc) return;
         ConvArgs a;
         base_args(a, c);
@@ -546,11 +570,26 @@ struct Runner {
         a.Hout = Hout; a.Wout = Wout;
         a.img = img; a.R = R; a.clamp = clamp;
         if (epi == EPI_FINAL) { a.Hi = Hout / R; a.Wi = Wout / R; }
+        double extra_flops = 0.0;
+        if (epi == EPI_FUSEDMIX) {
+            a.in1 = xin;
+            a.p1 = pad16(c.cout) * dtype_size(dtype) / 16;
+            a.wmix = mixf->packed;
+            a.mix_pieces = mixf->nchunks * mixf->nt;
+            {   // room for the 8 compute waves' x fragments next to the gate weights in ring slots 1-2?
+                const int a_slot = (mode == MODE_C3W16 ? 2 * 640 : 2 * 672) * 16;
+                const int slot = a_slot + 9 * c.nt * 1024;
+                const int ncx = a.p1 / 2;
+                a.x_via_lds = (a.mix_pieces * 1024 + 8 * ncx * 1024 <= 2 * slot) ? 1 : 0;
+            }
+            a.mix_scale = 1.0f / (1.0f + std::exp(-alpha));
+            extra_flops = 2.0 * (double)B * H * W * 2.0 * c.cout * c.cout;
+        }
         const double sz = dtype_size(dtype);
         const double px = (double)B * H * W;
         pick_order(a, c, px * c.cp0 * sz);
         ProfRec* r;
-        prof_begin(r, 2.0 * px * 9.0 * c.cin * c.cout, px * (c.cin + c.cout) * sz + 9.0 * c.cin * c.cout * sz, 1);
+        prof_begin(r, 2.0 * px * 9.0 * c.cin * c.cout + extra_flops, px * (c.cin + c.cout) * sz + 9.0 * c.cin * c.cout * sz, 1);
         if (r) { r->kind = 0; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.n_fast; }
         check(launch_conv(dtype, mode, c.nt, a, s), "conv3x3 launch");
         prof_end(r);
@@ -620,8 +659,13 @@ static int forward_micro(mz_handle* h, const char* x, char* out_sr, float* out_q
     auto block = [&](const BlockW& b, const void* xin, void* hid, void* z, void* yout, int hh, int ww) {
         // EncoderBlock / DecoderBlock (model.py:507-511): conv1 -> SiLU -> conv2 -> adaptive mix with the input
         run.conv3(b.conv1, xin, hid, nb, hh, ww, EPI_STORE, 1, 0, 0);
-        run.conv3(b.conv2, hid, z, nb, hh, ww, EPI_STORE, 0, 0, 0);
-        run.mix(b.mix, b.alpha, xin, z, yout, nb, hh, ww);
+        if (b.fused && run.wide_tiles && !run.no_fuse) {
+            // conv2 + AdaptiveResidualMix in one launch (all output channels live in one workgroup)
+            run.conv3(b.conv2, hid, yout, nb, hh, ww, EPI_FUSEDMIX, 0, 0, 0, nullptr, 0, 0, nullptr, &b.mixf, xin, b.alpha);
+        } else {
+            run.conv3(b.conv2, hid, z, nb, hh, ww, EPI_STORE, 0, 0, 0);
+            run.mix(b.mix, b.alpha, xin, z, yout, nb, hh, ww);
+        }
     };
 
     // stem (model.py:158): NCHW image -> NHWC features

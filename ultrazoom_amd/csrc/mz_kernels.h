@@ -21,12 +21,13 @@ inline int pad16(int c) { return (c + 15) / 16 * 16; }
 //                AdaptiveResidualMix gate) or SRC_CRUSH (2x2 stride-2 patch of in0 = PixelCrush).
 //   MODE_C3W16 / MODE_C3W8 : 3x3 on a 512-pixel tile (16 x 32 or 8 x 64) with 8 compute waves + 1 loader wave
 enum ConvMode : int { MODE_CONV3 = 0, MODE_GEMM1 = 1, MODE_C3W16 = 2, MODE_C3W8 = 3 };
-enum SrcKind : int { SRC_PLAIN = 0, SRC_CONCAT = 1, SRC_CRUSH = 2 };
+enum SrcKind : int { SRC_PLAIN = 0, SRC_CONCAT = 1, SRC_CRUSH = 2, SRC_MIXF = 3 /* pack-only: fused gate weights */ };
 enum Epilogue : int {
     EPI_STORE = 0,  // NHWC store (optional SiLU)
     EPI_D2S = 1,    // PixelShuffle(2) store into a [B,Hout,Wout,cq] tensor
     EPI_MIX = 2,    // out = x + s*sigmoid(acc)*(z - x), x = in0, z = in1
     EPI_FINAL = 3,  // PixelShuffle(2) + bicubic(img) + add (+clamp) -> NCHW image
+    EPI_FUSEDMIX = 4,  // conv2 of a block + AdaptiveResidualMix with the block input (in1) in one kernel
 };
 
 struct ConvArgs {
@@ -36,6 +37,9 @@ struct ConvArgs {
     void* out;
     const void* zero;  // >= 16 bytes of zeros in HBM (source for halo / out-of-range pixels)
     const void* img;   // EPI_FINAL: NCHW low-resolution image
+    const void* wmix;  // EPI_FUSEDMIX: gate weights packed with SRC_MIXF
+    int mix_pieces;    // EPI_FUSEDMIX: KiB of gate weights
+    int x_via_lds;     // EPI_FUSEDMIX: the block input's fragments are prefetched into LDS (room in ring slots 1-2)
     int B, H, W;       // input grid
     int Ho, Wo;        // output pixel grid of the GEMM (== H,W for CONV3; H/2,W/2 for CRUSH)
     int p0, p1;        // planes (16-byte channel groups) of in0 / in1: padded_channels * sizeof / 16

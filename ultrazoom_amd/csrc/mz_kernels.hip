@@ -289,12 +289,13 @@ __device__ __forceinline__ void run_items(f32x16 (&acc)[2][NT], Frags<NT>& cur, 
 //   IS_CONV: fragment mf covers pixels (ey[mf], ex[mf] + r) of image b;   else: linear pixels em[mf] + r.
 // ================================================================================================
 template <class TT, int NT, bool IS_CONV>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2][NT], char* ep, int lane, int nbase, int b,
-                                              const int (&ey)[2], const int (&ex)[2], const long long (&em)[2]) {
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const int epi, const int silu, f32x16 (&acc)[2][NT], char* ep,
+                                              int lane, int nbase, int b, const int (&ey)[2], const int (&ex)[2],
+                                              const long long (&em)[2]) {
     constexpr int SZ = TT::SZ;
     constexpr int BN = 32 * NT;
     const int h = lane >> 5, r = lane & 31;
-    if (a.epi == EPI_FINAL) {
+    if (epi == EPI_FINAL) {
         if (IS_CONV) {
             constexpr int ROWF = 80;  // 16 floats + 16 bytes pad
             const long long plane_i = (long long)a.Hi * a.Wi;
@@ -392,11 +393,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = acc[mf][nt][4 * q + j];
                 const int nloc = 32 * nt + 8 * q + 4 * h;
-                if (a.silu) {
+                if (silu) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = v[j] * sigmoidf_(v[j]);
                 }
-                if (a.epi == EPI_MIX) {
+                if (epi == EPI_MIX) {
                     float xv[4] = {0.f, 0.f, 0.f, 0.f}, zv[4] = {0.f, 0.f, 0.f, 0.f};
                     const int n = nbase + nloc;
                     if (bimg >= 0 && n < a.cp_out) {
@@ -419,7 +420,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
             const uint4 val = *(const uint4*)(ep + r * ROWB + cu * 16);
             const int n = nbase + cu * PPU;
             if (bimg < 0) continue;
-            if (IS_CONV && a.epi == EPI_D2S) {
+            if (IS_CONV && epi == EPI_D2S) {
                 if (n < 4 * a.cp_out) {
                     const int ij = n / a.cp_out;
                     const int c = n - ij * a.cp_out;
@@ -436,13 +437,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
 
 // ================================================================================================
 // 3x3 convolution, wide tile: 512 output pixels x BN channels per workgroup, 8 compute waves + 1 loader wave.
-//   - the weight stage (9 * NT KiB per K-chunk) is fetched ONCE for 512 pixels, by a dedicated wave, so the
-//     compute waves never pay the issue cost of the weight DMA;
+//   - the weight stage (9 * NT KiB per K-chunk) is fetched ONCE for 512 pixels, by a dedicated wave;
 //   - each compute wave issues only its 2-3 activation DMA instructions per stage;
-//   - 3-slot LDS ring, prefetch distance 2 stages, counted s_waitcnt vmcnt(N): the DMA of stage t+2 stays in
-//     flight across the single barrier of stage t.
+//   - 3-slot LDS ring [A0 B0 | A1 B1 | A2 B2], prefetch distance 2 stages, counted s_waitcnt vmcnt(N): the
+//     DMA of stage t+2 stays in flight across the single barrier of stage t.  The ring is rotated so that the
+//     LAST stage sits in slot 0: slots 1-2 are then one contiguous free region during the last stage(s).
+//   - FUSE: the AdaptiveResidualMix that follows conv2 of a block (reference model.py:507-511, 826-839) runs in
+//     the epilogue.  With BN == all channels every wave owns all channels of its 64 pixels, so the gate
+//     beta = Wx.x + Wz.z is wave-local: z goes from the accumulators straight into the MFMA B operand (the
+//     accumulator rows are the K index; the gate weights are packed in that row order), x fragments come
+//     from HBM as plain 16-byte loads (plane-major layout), and the gate weights are prefetched by the loader
+//     wave into ring slots 1-2 while the last K-stage is being computed.
 // ================================================================================================
-// -DMZ_STAMP: diagnostic build that records where one workgroup's waves spend each stage (never shipped)
+// -DMZ_STAMP=2: diagnostic build that records where one workgroup's waves spend each K-stage (never shipped);
+// -DMZ_STAMP=1 only records the in-kernel clock probe.
 #if defined(MZ_STAMP) && MZ_STAMP >= 2
 #define STAMP(k)                                                                                                  \
     do {                                                                                                          \
@@ -457,19 +465,57 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
 #endif
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-#ifndef MZ_NLOAD
-#define MZ_NLOAD 1
-#endif
-#ifndef MZ_LOADER_SLEEP
-#define MZ_LOADER_SLEEP 0
-#endif
-#ifndef MZ_STAGGER
-#define MZ_STAGGER 0
-#endif
-static constexpr int NLOAD = MZ_NLOAD;  // weight-loader waves per workgroup
+// z accumulators -> MFMA B-operand fragments, and back to the (rounded) values for the blend
+template <class TT> struct ZFrag;
+template <> struct ZFrag<TF32> {
+    static constexpr int ZG = 4;  // fragments per 32-row accumulator tile
+    static __device__ __forceinline__ u32x4 make(const f32x16& t, int g) {
+        // (copy each element to a scalar first: __builtin_bit_cast applied to an ext-vector element reads element 0)
+        const float e0 = t[4 * g + 0], e1 = t[4 * g + 1], e2 = t[4 * g + 2], e3 = t[4 * g + 3];
+        u32x4 f;
+        f[0] = __builtin_bit_cast(uint32_t, e0); f[1] = __builtin_bit_cast(uint32_t, e1);
+        f[2] = __builtin_bit_cast(uint32_t, e2); f[3] = __builtin_bit_cast(uint32_t, e3);
+        return f;
+    }
+    static __device__ __forceinline__ void quad(const u32x4 (&f)[4], int q, float v[4]) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const f32x4 t = __builtin_bit_cast(f32x4, f[q]);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    }
+};
+template <> struct ZFrag<TBF16> {
+    static constexpr int ZG = 2;
+    static __device__ __forceinline__ u32x4 make(const f32x16& t, int g) {
+        u32x4 f;
+        f[0] = pack_bf16(t[8 * g + 0], t[8 * g + 1]); f[1] = pack_bf16(t[8 * g + 2], t[8 * g + 3]);
+        f[2] = pack_bf16(t[8 * g + 4], t[8 * g + 5]); f[3] = pack_bf16(t[8 * g + 6], t[8 * g + 7]);
+        return f;
+    }
+    static __device__ __forceinline__ void quad(const u32x4 (&f)[2], int q, float v[4]) {
+        const u32x4 t = f[q >> 1];
+        const uint32_t lo = (q & 1) ? t[2] : t[0], hi = (q & 1) ? t[3] : t[1];
+        v[0] = __builtin_bit_cast(float, lo << 16); v[1] = __builtin_bit_cast(float, lo & 0xffff0000u);
+        v[2] = __builtin_bit_cast(float, hi << 16); v[3] = __builtin_bit_cast(float, hi & 0xffff0000u);
+    }
+};
+template <> struct ZFrag<TF16> {
+    static constexpr int ZG = 2;
+    static __device__ __forceinline__ u32x4 make(const f32x16& t, int g) {
+        u32x4 f;
+        f[0] = pack_f16(t[8 * g + 0], t[8 * g + 1]); f[1] = pack_f16(t[8 * g + 2], t[8 * g + 3]);
+        f[2] = pack_f16(t[8 * g + 4], t[8 * g + 5]); f[3] = pack_f16(t[8 * g + 6], t[8 * g + 7]);
+        return f;
+    }
+    static __device__ __forceinline__ void quad(const u32x4 (&f)[2], int q, float v[4]) {
+        const u32x4 t = f[q >> 1];
+        const uint32_t lo = (q & 1) ? t[2] : t[0], hi = (q & 1) ? t[3] : t[1];
+        v[0] = (float)__builtin_bit_cast(_Float16, (uint16_t)(lo & 0xffff)); v[1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(lo >> 16));
+        v[2] = (float)__builtin_bit_cast(_Float16, (uint16_t)(hi & 0xffff)); v[3] = (float)__builtin_bit_cast(_Float16, (uint16_t)(hi >> 16));
+    }
+};
 
-template <class TT, int NT, int MODE>
-__global__ __launch_bounds__(512 + 64 * NLOAD, 3) void conv3w_kernel(const ConvArgs a) {
+template <class TT, int NT, int MODE, bool FUSE>
+__global__ __launch_bounds__(576, 3) void conv3w_kernel(const ConvArgs a) {
     using G = Geo<MODE>;
     constexpr int SZ = TT::SZ;
     constexpr int BN = 32 * NT;
@@ -477,12 +523,13 @@ __global__ __launch_bounds__(512 + 64 * NLOAD, 3) void conv3w_kernel(const ConvA
     constexpr int A_INSTR = G::A_ENT / 64;
     constexpr int B_PIECES = 9 * NT;
     constexpr int B_SLOT = B_PIECES * 1024;
+    constexpr int SLOT = A_SLOT + B_SLOT;
     static_assert(B_PIECES < 60, "vmcnt is a 6-bit counter");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7 compute, 8.. = weight loaders
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7 compute, 8 = weight loader
     const int h = lane >> 5;
     const int r = lane & 31;
 
@@ -502,43 +549,45 @@ __global__ __launch_bounds__(512 + 64 * NLOAD, 3) void conv3w_kernel(const ConvA
     }
     const int nbase = ntile * BN;
     const int nstages = a.nchunks;
-    char* const Bring = smem + 3 * A_SLOT;
+    const int last = nstages - 1;
+    const int s0 = (3 - last % 3) % 3;  // slot(st) = (st + s0) % 3, so slot(last) == 0
+    char* const mixw = smem + SLOT;     // FUSE: gate weights live in slots 1-2 once those are free
 
-    if (w >= 8) {
-        // ------------------------- weight loader waves -------------------------
-        // loader li takes pieces li, li + NLOAD, ... of every stage (a piece = 1 KiB = one DMA instruction)
-        const int li = w - 8;
-        constexpr int MAXP = (B_PIECES + NLOAD - 1) / NLOAD;
-        const int myp = (B_PIECES - li + NLOAD - 1) / NLOAD;  // MAXP or MAXP - 1
-        const char* wsrc = (const char*)a.wpk + (size_t)ntile * a.nchunks * (B_PIECES * 1024) + lane * 16 + li * 1024;
+    if (w == 8) {
+        // ------------------------- weight loader wave -------------------------
+        const char* wsrc = (const char*)a.wpk + (size_t)ntile * a.nchunks * (B_PIECES * 1024) + lane * 16;
         auto loadB = [&](int st, int slot) {
-            const char* src = wsrc + (size_t)((MZ_ABLATE & 32) ? 0 : st) * (B_PIECES * 1024);  // 32: always stage 0 (L2-hot)
-            char* dst = Bring + slot * B_SLOT + li * 1024;
+            const char* src = wsrc + (size_t)st * (B_PIECES * 1024);
+            char* dst = smem + slot * SLOT + A_SLOT;
 #pragma unroll
-            for (int j = 0; j < MAXP; ++j) {
-                if (j < myp) glds16(src + j * (NLOAD * 1024), dst + j * (NLOAD * 1024));
-                if (MZ_LOADER_SLEEP > 0) __builtin_amdgcn_s_sleep(MZ_LOADER_SLEEP);  // pace the DMA: no burst at stage start
-            }
+            for (int j = 0; j < B_PIECES; ++j) glds16(src + j * 1024, dst + j * 1024);
         };
-        loadB(0, 0);
-        if (nstages > 1) loadB(1, 1);
-        int slot2 = 2;  // slot of stage st + 2
+        int sl = s0;
+        loadB(0, sl);
+        sl = sl == 2 ? 0 : sl + 1;
+        if (nstages > 1) loadB(1, sl);
+        sl = sl == 2 ? 0 : sl + 1;  // slot of stage st + 2
+        const int mix1 = FUSE ? (a.mix_pieces < SLOT / 1024 ? a.mix_pieces : SLOT / 1024) : 0;  // pieces that fit slot 1
         for (int st = 0; st < nstages; ++st) {
             STAMP(0);
-            if (st + 1 < nstages) {
-                if (myp == MAXP) wait_vmcnt<MAXP>(); else wait_vmcnt<MAXP - 1>();
-            } else {
-                wait_vmcnt<0>();
-            }
+            if (st + 1 < nstages) wait_vmcnt<B_PIECES>(); else wait_vmcnt<0>();
             STAMP(1);
             __builtin_amdgcn_s_barrier();
             STAMP(2);
-            if (st + 2 < nstages && !(MZ_ABLATE & 16)) loadB(st + 2, slot2);
+            if (st + 2 < nstages && !(MZ_ABLATE & 16)) loadB(st + 2, sl);
+            if (FUSE) {
+                const char* msrc = (const char*)a.wmix + lane * 16;
+                if (st == (last > 0 ? last - 1 : 0))  // slot 1 was last read in stage last-2: free after this barrier
+                    for (int j = 0; j < mix1; ++j) glds16(msrc + j * 1024, mixw + j * 1024);
+                if (st == last)                       // slot 2 was last read in stage last-1
+                    for (int j = mix1; j < a.mix_pieces; ++j) glds16(msrc + j * 1024, mixw + j * 1024);
+            }
             STAMP(3);
-            slot2 = slot2 == 2 ? 0 : slot2 + 1;
+            sl = sl == 2 ? 0 : sl + 1;
         }
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
+        if (FUSE) __builtin_amdgcn_s_barrier();  // the compute waves' barrier between the gate GEMM and the stores
         return;
     }
 
@@ -565,8 +614,8 @@ __global__ __launch_bounds__(512 + 64 * NLOAD, 3) void conv3w_kernel(const ConvA
     }
     const int nA = (A_INSTR - w + 7) / 8;  // 2 or 3 instructions per stage for this wave
     auto loadA = [&](int st, int slot) {
-        const long long kbyte = (MZ_ABLATE & 64) ? 0 : 2LL * st * plane_in;  // 64: always chunk 0 (cache-hot)
-        char* dst = smem + slot * A_SLOT;
+        const long long kbyte = 2LL * st * plane_in;
+        char* dst = smem + slot * SLOT;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             if (w + 8 * i >= A_INSTR) break;
@@ -574,8 +623,12 @@ __global__ __launch_bounds__(512 + 64 * NLOAD, 3) void conv3w_kernel(const ConvA
             glds16(src, dst + (w + 8 * i) * 1024);
         }
     };
-    loadA(0, 0);
-    if (nstages > 1) loadA(1, 1);
+    int slot = s0;
+    int sl2 = s0;
+    loadA(0, sl2);
+    sl2 = sl2 == 2 ? 0 : sl2 + 1;
+    if (nstages > 1) loadA(1, sl2);
+    sl2 = sl2 == 2 ? 0 : sl2 + 1;  // slot of stage st + 2
 #ifdef MZ_STAMP
     if (a.dbg && w == 0 && lane == 0 && (blockIdx.x & 255) == 7) {  // clock probe: shader cycles vs 100 MHz real time
         unsigned long long t_, r_;
@@ -595,9 +648,31 @@ __global__ __launch_bounds__(512 + 64 * NLOAD, 3) void conv3w_kernel(const ConvA
 
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const uint32_t a_lane = lds_base + h * G::PLANE + ((G::ROW_PER_WAVE * w) * G::ROWW + r) * 16;
-    const uint32_t b_lane = lds_base + 3 * A_SLOT + lane * 16;
+    const uint32_t b_lane = lds_base + A_SLOT + lane * 16;
 
-    int slot = 0, slot2 = 2;
+    // pixel geometry of this wave's two M fragments
+    int ey[2], ex[2];
+    if (G::ROW_PER_WAVE == 2) {
+        ey[0] = y0 + 2 * w; ey[1] = y0 + 2 * w + 1;
+        ex[0] = x0; ex[1] = x0;
+    } else {
+        ey[0] = y0 + w; ey[1] = y0 + w;
+        ex[0] = x0; ex[1] = x0 + 32;
+    }
+    // FUSE: the block input x as MFMA B fragments, fetched by LDS-DMA into this wave's corner of ring slots 1-2
+    const int ncx = FUSE ? a.p1 / 2 : 0;  // K-chunks of x (two planes per chunk)
+    const long long plane_x = (long long)a.H * a.W * 16;
+    char* const xr = mixw + (FUSE ? a.mix_pieces * 1024 + w * (ncx * 1024) : 0);
+    auto pix_ok = [&](int mf) { return ey[mf] < a.H && ex[mf] + r < a.W; };
+    auto x_base = [&](int mf) {
+        return (const char*)a.in1 + ((((long long)b * a.p1) * a.H + ey[mf]) * a.W + ex[mf] + r) * 16;
+    };
+    auto x_dma = [&](int mf) {  // entry (chunk c, lane (h, r)) = plane 2c + h of pixel r
+        const bool ok = pix_ok(mf);
+        const char* xb = x_base(mf);
+        for (int c = 0; c < ncx; ++c) glds16(ok ? xb + (2LL * c + h) * plane_x : (const char*)a.zero, xr + c * 1024);
+    };
+
     for (int st = 0; st < nstages; ++st) {
         // my own activation DMA of stage st has landed once at most the newer stage's instructions are pending
         STAMP(0);
@@ -609,24 +684,22 @@ __global__ __launch_bounds__(512 + 64 * NLOAD, 3) void conv3w_kernel(const ConvA
         STAMP(1);
         __builtin_amdgcn_s_barrier();  // stage st is complete in LDS; everyone is done reading stage st-1
         STAMP(2);
-        if (st + 2 < nstages && !(MZ_ABLATE & 8)) loadA(st + 2, slot2);
+        if (st + 2 < nstages && !(MZ_ABLATE & 8)) loadA(st + 2, sl2);
+        if (FUSE && st == last && a.x_via_lds) x_dma(0);  // slots 1-2 are free from here on; lands under this stage's MFMAs
         STAMP(3);
-        // Waves w and w+4 share a SIMD and run the same program: without a stagger they hit the LDS together and
-        // then the matrix pipe together, so the two resources are used in turns instead of concurrently.
-        if (MZ_STAGGER > 0 && w >= 4) __builtin_amdgcn_s_sleep(MZ_STAGGER);
 
-        const uint32_t a_addr = a_lane + slot * A_SLOT;
-        const uint32_t b_addr = b_lane + slot * B_SLOT;
+        const uint32_t a_addr = a_lane + slot * SLOT;
+        const uint32_t b_addr = b_lane + slot * SLOT;
         Frags<NT> fa, fb;
         issue_reads<NT, MODE, 0>(fa, a_addr, b_addr);
         wait_frags<NT>(fa);
         run_items<TT, NT, MODE, 0, 9>(acc, fa, fb, a_addr, b_addr);
         STAMP(4);
         slot = slot == 2 ? 0 : slot + 1;
-        slot2 = slot2 == 2 ? 0 : slot2 + 1;
+        sl2 = sl2 == 2 ? 0 : sl2 + 1;
     }
     wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();  // all fragment reads are done: the ring may be reused by the epilogue
+    __builtin_amdgcn_s_barrier();  // all fragment reads are done (and, FUSE, the gate weights have landed)
 #ifdef MZ_STAMP
     if (a.dbg && w == 0 && lane == 0 && (blockIdx.x & 255) == 7) {
         unsigned long long t_, r_;
@@ -636,18 +709,131 @@ __global__ __launch_bounds__(512 + 64 * NLOAD, 3) void conv3w_kernel(const ConvA
     }
 #endif
 
-    {
-        constexpr int EPW = 32 * (BN * SZ + 16) > 32 * 80 ? 32 * (BN * SZ + 16) : 32 * 80;
-        int ey[2], ex[2];
-        if (G::ROW_PER_WAVE == 2) {
-            ey[0] = y0 + 2 * w; ey[1] = y0 + 2 * w + 1;
-            ex[0] = x0; ex[1] = x0;
-        } else {
-            ey[0] = y0 + w; ey[1] = y0 + w;
-            ex[0] = x0; ex[1] = x0 + 32;
+    constexpr int EPW = 32 * (BN * SZ + 16) > 32 * 80 ? 32 * (BN * SZ + 16) : 32 * 80;
+    const long long em[2] = {0, 0};
+
+    if (FUSE) {
+        // ---- AdaptiveResidualMix in registers: acc = z (conv2 output), x = a.in1 (the block input) ----
+        using Z = ZFrag<TT>;
+        constexpr int ZG = Z::ZG;
+        constexpr int PPU = SZ == 2 ? 8 : 4;
+        // Register diet (the 9-wave workgroup caps a wave at 168 VGPRs): z of BOTH fragments is packed to the storage
+        // type first (the unfused path rounds z the same way when it stores it), the accumulators die, and each
+        // fragment's blended result is packed again until the store phase.
+        u32x4 zf[2][NT][ZG];
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < ZG; ++g) {
+                    zf[mf][nt][g] = Z::make(acc[mf][nt], g);
+                    // opaque: stops hipcc from forwarding pack -> unpack and keeping 96 unpacked floats alive
+                    asm volatile("" : "+v"(zf[mf][nt][g]));
+                }
+        u32x4 res[2][NT][ZG];
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf) {
+            const bool inside = pix_ok(mf);
+            const char* xbase = x_base(mf);
+            f32x16 beta[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) beta[nt][i] = 0.0f;
+            // gate, z half: accumulator rows are the K index (weights were packed in that row order)
+            const char* wz = mixw + ncx * NT * 1024 + lane * 16;
+#pragma unroll
+            for (int ntz = 0; ntz < NT; ++ntz)
+#pragma unroll
+                for (int g = 0; g < ZG; ++g) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const u32x4 wv = *(const u32x4*)(wz + ((ntz * ZG + g) * NT + nt) * 1024);
+                        mma<TT>(beta[nt], wv, zf[mf][ntz][g]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // keep hipcc from hoisting every weight fragment read up front
+                }
+            // gate, x half
+            if (a.x_via_lds) {
+                if (mf == 1) wait_vmcnt<0>();  // mf 1's fragments were requested after mf 0's blend (below)
+                for (int c = 0; c < ncx; ++c) {
+                    const u32x4 xf = *(const u32x4*)(xr + c * 1024 + lane * 16);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const u32x4 wv = *(const u32x4*)(mixw + (c * NT + nt) * 1024 + lane * 16);
+                        mma<TT>(beta[nt], wv, xf);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                for (int c0 = 0; c0 < ncx; c0 += 2) {  // straight from HBM, two K-chunks in flight (register budget)
+                    u32x4 xf[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        xf[i] = u32x4{0u, 0u, 0u, 0u};
+                        if (inside && c0 + i < ncx) xf[i] = *(const u32x4*)(xbase + (2LL * (c0 + i) + h) * plane_x);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        if (c0 + i < ncx) {
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+                                const u32x4 wv = *(const u32x4*)(mixw + ((c0 + i) * NT + nt) * 1024 + lane * 16);
+                                mma<TT>(beta[nt], wv, xf[i]);
+                            }
+                        }
+                    }
+                }
+            }
+            // blend: out = x + sigmoid(alpha) * sigmoid(beta) * (z - x), in place, one quad at a time
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float xv[4] = {0.f, 0.f, 0.f, 0.f}, zv[4];
+                    Z::quad(zf[mf][nt], q, zv);
+                    const int n = 32 * nt + 8 * q + 4 * h;
+                    if (a.x_via_lds) {
+                        // channels n..n+3 of pixel r sit in chunk n / CK, plane (n / PPU) & 1 of the fragment image
+                        const int plane = n / PPU, inner = (n - plane * PPU) * SZ;
+                        if (plane < a.p1) ld4<TT>(xr + (plane >> 1) * 1024 + ((plane & 1) * 32 + r) * 16 + inner, xv);
+                    } else if (inside && n < a.cp_out) {
+                        const int plane = n / PPU, inner = (n - plane * PPU) * SZ;
+                        ld4<TT>(xbase + plane * plane_x + inner, xv);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        beta[nt][4 * q + j] = xv[j] + a.mix_scale * sigmoidf_(beta[nt][4 * q + j]) * (zv[j] - xv[j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int g = 0; g < ZG; ++g) {
+                    res[mf][nt][g] = Z::make(beta[nt], g);
+                    asm volatile("" : "+v"(res[mf][nt][g]));
+                }
+            }
+            if (a.x_via_lds && mf == 0) {
+                __builtin_amdgcn_wave_barrier();
+                x_dma(1);  // overlaps mf 1's z-half MFMAs
+            }
         }
-        const long long em[2] = {0, 0};
-        conv_epilogue<TT, NT, true>(a, acc, smem + w * EPW, lane, nbase, b, ey, ex, em);
+        // unpack the (already rounded) results back into the accumulator registers for the common store path
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[4];
+                    Z::quad(res[mf][nt], q, v);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[mf][nt][4 * q + j] = v[j];
+                }
+        __builtin_amdgcn_s_barrier();  // every wave is done with the gate weights: the ring can take epilogue data
+        conv_epilogue<TT, NT, true>(a, EPI_STORE, 0, acc, smem + w * EPW, lane, nbase, b, ey, ex, em);
+    } else {
+        conv_epilogue<TT, NT, true>(a, a.epi, a.silu, acc, smem + w * EPW, lane, nbase, b, ey, ex, em);
     }
 }
 
@@ -835,7 +1021,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
         const int ey[2] = {y0 + 2 * w, y0 + 2 * w + 1};
         const int ex[2] = {x0, x0};
         const long long em[2] = {m0 + 64 * w, m0 + 64 * w + 32};
-        conv_epilogue<TT, NT, MODE == MODE_CONV3>(a, acc, smem + w * EPW, lane, nbase, b, ey, ex, em);
+        conv_epilogue<TT, NT, MODE == MODE_CONV3>(a, a.epi, a.silu, acc, smem + w * EPW, lane, nbase, b, ey, ex, em);
     }
 }
 
@@ -873,7 +1059,10 @@ template <class TT, int NT, int MODE> static hipError_t launch_one(const ConvArg
     const size_t lds = conv_lds_bytes(MODE, NT);
     if constexpr (MODE == MODE_C3W16 || MODE == MODE_C3W8) {
         if constexpr (NT <= 3) {
-            hipLaunchKernelGGL((conv3w_kernel<TT, NT, MODE>), dim3(a.mtiles * a.ntiles), dim3(512 + 64 * NLOAD), lds, s, a);
+            if (a.epi == EPI_FUSEDMIX)
+                hipLaunchKernelGGL((conv3w_kernel<TT, NT, MODE, true>), dim3(a.mtiles * a.ntiles), dim3(576), lds, s, a);
+            else
+                hipLaunchKernelGGL((conv3w_kernel<TT, NT, MODE, false>), dim3(a.mtiles * a.ntiles), dim3(576), lds, s, a);
         } else {
             return hipErrorInvalidValue;
         }
@@ -911,10 +1100,16 @@ hipError_t launch_conv(int dtype, int mode, int nt, const ConvArgs& a, hipStream
 }
 
 template <class TT, int NT, int MODE> static hipError_t set_lds_one() {
-    const void* fn;
-    if constexpr (MODE == MODE_C3W16 || MODE == MODE_C3W8) fn = (const void*)conv3w_kernel<TT, NT, MODE>;
-    else fn = (const void*)conv_kernel<TT, NT, MODE>;
-    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_lds_bytes(MODE, NT));
+    const int bytes = (int)conv_lds_bytes(MODE, NT);
+    if constexpr (MODE == MODE_C3W16 || MODE == MODE_C3W8) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3w_kernel<TT, NT, MODE, false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        return hipFuncSetAttribute((const void*)conv3w_kernel<TT, NT, MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   bytes);
+    } else {
+        return hipFuncSetAttribute((const void*)conv_kernel<TT, NT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    }
 }
 template <class TT> static hipError_t set_lds_all() {
     hipError_t e;
@@ -976,6 +1171,19 @@ template <class TT> __global__ void pack_kernel(const PackArgs a, long long tota
         const int k = kc * CK + kin;
         if (k < a.cp0) ci = k < a.c0 ? k : -1;
         else ci = (k - a.cp0) < a.c1 ? a.c0 + (k - a.cp0) : -1;
+    } else if (a.in_map == SRC_MIXF) {
+        // fused AdaptiveResidualMix gate: chunks [0, ncx) = x channels in natural order; then one chunk per
+        // (32-row accumulator tile, fragment g) of z, K-elements in ACCUMULATOR ROW order (ZFrag<TT>::make)
+        const int ncx = a.cp0 / CK;
+        if (kc < ncx) {
+            const int k = kc * CK + kin;
+            ci = k < a.c0 ? k : -1;
+        } else {
+            constexpr int ZG = SZ == 2 ? 2 : 4;
+            const int gz = kc - ncx, ntz = gz / ZG, g = gz - ntz * ZG;
+            const int zrow = 32 * ntz + (SZ == 2 ? 16 * g + 8 * (e >> 2) + 4 * hh + (e & 3) : 8 * g + 4 * hh + e);
+            ci = zrow < a.c1 ? a.c0 + zrow : -1;
+        }
     } else {  // CRUSH: K axis = [tap][padded channel]
         const int cpt = a.cp0 / CK;  // chunks per tap
         const int st = kc / cpt;
