@@ -100,7 +100,10 @@ template <> __device__ __forceinline__ void ld4<TF16>(const void* p, float v[4])
     v[3] = (float)__builtin_bit_cast(_Float16, (uint16_t)(t.y >> 16));
 }
 
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+// sigmoid with the hardware transcendental units: v_exp_f32 + v_rcp_f32 (1 ulp each) instead of an IEEE division
+__device__ __forceinline__ float sigmoidf_(float v) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+}
 
 // ---- one K-chunk of matrix work: acc[n][pixel] += W[n][k] * X[pixel][k] ------------------------
 template <class TT> __device__ __forceinline__ void mma(f32x16& acc, const u32x4& w, const u32x4& x);
