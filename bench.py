@@ -241,7 +241,7 @@ def main():
             },
         }
         if not args.no_cpu_baseline and world == 1:
-            sample = (192, 320) if model_name == "4x96" else (256, 256)
+            sample = (384, 640) if model_name == "4x96" else (540, 960)  # ~10-20 s of CPU work in total
             result["cpu_baseline"] = cpu_baseline(cfg, sd, model, dtype, sample)
         print(json.dumps(result), flush=True)
     if world > 1:
