@@ -534,12 +534,26 @@ struct Runner {
         a.use_glds = h ? h->use_glds : 1;
     }
 
-    void pick_order(ConvArgs& a, const ConvW& c, double act_bytes) {
-        // Walk N tiles fastest when re-streaming the weights per pixel tile is cheaper than
-        // re-reading the activations per N tile (both from L2 / Infinity Cache).
-        const double w_traffic = (double)a.mtiles * (double)c.packed_sz;
-        const double a_traffic = (double)a.ntiles * act_bytes;
-        a.n_fast = (a.ntiles == 1 || w_traffic <= a_traffic) ? 1 : 0;
+    void pick_order(ConvArgs& a, const ConvW& c, double act_bytes, int resident_per_xcd = 32) {
+        // Tile groups of gm pixel tiles x gn N tiles (gm * gn ~ the workgroups resident on one XCD): inside a group
+        // both operands are shared through the XCD's L2; per group the activations are re-read ntiles/gn times and
+        // the weights mtiles/gm times in total.  Pick the shape with the least total re-read traffic.
+        const double W = (double)c.packed_sz, A = act_bytes;
+        int best_gm = a.mtiles, best_gn = 1;
+        double best = 1e300;
+        for (int gn = 1; gn <= a.ntiles; ++gn) {
+            if (gn > resident_per_xcd) break;
+            if (a.ntiles % gn != 0 && gn != a.ntiles) continue;
+            int gm = resident_per_xcd / gn;
+            if (gm < 1) gm = 1;
+            if (gm > a.mtiles) gm = a.mtiles;
+            const double groups_n = std::ceil((double)a.ntiles / gn), groups_m = std::ceil((double)a.mtiles / gm);
+            const double traffic = A * groups_n + W * groups_m;
+            if (traffic < best) { best = traffic; best_gm = gm; best_gn = gn; }
+        }
+        a.gm = best_gm; a.gn = best_gn;
+        const long long groups = (long long)((a.mtiles + a.gm - 1) / a.gm) * ((a.ntiles + a.gn - 1) / a.gn);
+        a.grid = (int)(groups * a.gm * a.gn);
     }
 
     // conv3x3, pad 1 (model.py:742-748, 900-909, 1010). epi: STORE / D2S / FINAL
@@ -590,7 +604,7 @@ struct Runner {
         pick_order(a, c, px * c.cp0 * sz);
         ProfRec* r;
         prof_begin(r, 2.0 * px * 9.0 * c.cin * c.cout + extra_flops, px * (c.cin + c.cout) * sz + 9.0 * c.cin * c.cout * sz, 1);
-        if (r) { r->kind = 0; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.n_fast; }
+        if (r) { r->kind = 0; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.gm * 1000 + a.gn; }
         check(launch_conv(dtype, mode, c.nt, a, s), "conv3x3 launch");
         prof_end(r);
     }
@@ -612,10 +626,10 @@ struct Runner {
         a.cp_out = pad16(c.cout);
         a.p_out = a.cp_out * sz / 16;
         a.mix_scale = 1.0f / (1.0f + std::exp(-alpha));
-        pick_order(a, c, (double)npix * (c.cp0 + pad16(c.c1)) * sz);
+        pick_order(a, c, (double)npix * (c.cp0 + pad16(c.c1)) * sz, 64);
         ProfRec* r;
         prof_begin(r, 2.0 * (double)npix * c.cin * c.cout, (double)npix * 3.0 * c.cout * sz, 0);
-        if (r) { r->kind = 1; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.n_fast; }
+        if (r) { r->kind = 1; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.gm * 1000 + a.gn; }
         check(launch_conv(dtype, MODE_GEMM1, c.nt, a, s), "mix launch");
         prof_end(r);
     }
@@ -637,10 +651,10 @@ struct Runner {
         a.cp_out = pad16(c.cout);
         a.p_out = a.cp_out * dtype_size(dtype) / 16;
         const double sz = dtype_size(dtype);
-        pick_order(a, c, (double)B * H * W * c.cp0 * sz);
+        pick_order(a, c, (double)B * H * W * c.cp0 * sz, 64);
         ProfRec* r;
         prof_begin(r, 2.0 * (double)npix * 4.0 * c.cin * c.cout, ((double)B * H * W * c.cin + (double)npix * c.cout) * sz, 0);
-        if (r) { r->kind = 2; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.n_fast; }
+        if (r) { r->kind = 2; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.gm * 1000 + a.gn; }
         check(launch_conv(dtype, MODE_GEMM1, c.nt, a, s), "crush launch");
         prof_end(r);
     }

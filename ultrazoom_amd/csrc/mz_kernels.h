@@ -51,7 +51,8 @@ struct ConvArgs {
     int ntiles;        // N tiles (of 32*NT channels)
     int mtiles;        // pixel tiles
     int tiles_x, tiles_y;  // CONV3: tiles per image
-    int n_fast;        // 1: consecutive workgroups walk the N tiles of one pixel tile
+    int gm, gn;        // tile-group shape of the workgroup -> tile walk (map_tile)
+    int grid;          // workgroups launched: whole groups, >= mtiles * ntiles
     int epi;
     int silu;
     int cp_out;        // STORE/MIX: padded channels of out; D2S: channels per output pixel (cq_p)

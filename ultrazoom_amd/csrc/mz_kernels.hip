@@ -286,6 +286,27 @@ __device__ __forceinline__ void run_items(f32x16 (&acc)[2][NT], Frags<NT>& cur, 
 }
 
 // ================================================================================================
+// workgroup -> (pixel tile, N tile).  Consecutive logical ids land on one XCD (bijective remap of the round-robin
+// dispatch), and within an XCD's contiguous id range tiles are walked in gm x gn groups: the ~32 workgroups that are
+// resident on an XCD together then share gm activation tiles and gn weight tiles through that XCD's L2 instead of
+// re-streaming one operand per tile of the other.  Returns false for the padding ids of a partial group.
+// ================================================================================================
+__device__ __forceinline__ bool map_tile(const ConvArgs& a, int& mtile, int& ntile) {
+    const int nblk = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q = nblk >> 3, rem = nblk & 7, xcd = bid & 7, pos = bid >> 3;
+    const int L = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + pos;
+    const int gsz = a.gm * a.gn;
+    const int group = L / gsz, within = L - group * gsz;
+    const int groups_m = (a.mtiles + a.gm - 1) / a.gm;
+    const int gi_n = group / groups_m, gi_m = group - gi_n * groups_m;
+    const int mi = within / a.gn, ni = within - mi * a.gn;
+    mtile = gi_m * a.gm + mi;
+    ntile = gi_n * a.gn + ni;
+    return mtile < a.mtiles && ntile < a.ntiles;
+}
+
+// ================================================================================================
 // epilogue, shared by every convolution kernel.  Wave-local: each wave transposes its own 64-pixel x BN tile
 // through its own LDS region `ep`, so no workgroup barrier is needed (LDS operations of one wave execute in
 // program order).  Pixel geometry of the wave's two M fragments:
@@ -537,19 +558,7 @@ __global__ __launch_bounds__(576, 3) void conv3w_kernel(const ConvArgs a) {
     const int r = lane & 31;
 
     int mtile, ntile;
-    {
-        const int nblk = a.mtiles * a.ntiles;
-        const int bid = blockIdx.x;
-        const int q = nblk >> 3, rem = nblk & 7, xcd = bid & 7, pos = bid >> 3;
-        const int L = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + pos;
-        if (a.n_fast) {
-            mtile = L / a.ntiles;
-            ntile = L - mtile * a.ntiles;
-        } else {
-            ntile = L / a.mtiles;
-            mtile = L - ntile * a.mtiles;
-        }
-    }
+    if (!map_tile(a, mtile, ntile)) return;  // padding id of a partial tile group (whole workgroup, uniform)
     const int nbase = ntile * BN;
     const int nstages = a.nchunks;
     const int last = nstages - 1;
@@ -861,19 +870,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
 
     // ---- workgroup -> (pixel tile, N tile); consecutive logical ids share an XCD (and its L2) ----
     int mtile, ntile;
-    {
-        const int nblk = a.mtiles * a.ntiles;
-        const int bid = blockIdx.x;
-        const int q = nblk >> 3, rem = nblk & 7, xcd = bid & 7, pos = bid >> 3;
-        const int L = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + pos;
-        if (a.n_fast) {
-            mtile = L / a.ntiles;
-            ntile = L - mtile * a.ntiles;
-        } else {
-            ntile = L / a.mtiles;
-            mtile = L - ntile * a.mtiles;
-        }
-    }
+    if (!map_tile(a, mtile, ntile)) return;  // padding id of a partial tile group (whole workgroup, uniform)
     const int nbase = ntile * BN;
     const char* wtile = (const char*)a.wpk + (size_t)ntile * a.nchunks * (TAPS * NT * 1024);
 
@@ -1063,14 +1060,14 @@ template <class TT, int NT, int MODE> static hipError_t launch_one(const ConvArg
     if constexpr (MODE == MODE_C3W16 || MODE == MODE_C3W8) {
         if constexpr (NT <= 3) {
             if (a.epi == EPI_FUSEDMIX)
-                hipLaunchKernelGGL((conv3w_kernel<TT, NT, MODE, true>), dim3(a.mtiles * a.ntiles), dim3(576), lds, s, a);
+                hipLaunchKernelGGL((conv3w_kernel<TT, NT, MODE, true>), dim3(a.grid), dim3(576), lds, s, a);
             else
-                hipLaunchKernelGGL((conv3w_kernel<TT, NT, MODE, false>), dim3(a.mtiles * a.ntiles), dim3(576), lds, s, a);
+                hipLaunchKernelGGL((conv3w_kernel<TT, NT, MODE, false>), dim3(a.grid), dim3(576), lds, s, a);
         } else {
             return hipErrorInvalidValue;
         }
     } else {
-        hipLaunchKernelGGL((conv_kernel<TT, NT, MODE>), dim3(a.mtiles * a.ntiles), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((conv_kernel<TT, NT, MODE>), dim3(a.grid), dim3(256), lds, s, a);
     }
     return hipGetLastError();
 }
@@ -1093,7 +1090,7 @@ template <class TT> static hipError_t launch_mode(int mode, int nt, const ConvAr
     return hipErrorInvalidValue;
 }
 hipError_t launch_conv(int dtype, int mode, int nt, const ConvArgs& a, hipStream_t s) {
-    if (a.mtiles <= 0 || a.ntiles <= 0) return hipErrorInvalidValue;
+    if (a.mtiles <= 0 || a.ntiles <= 0 || a.gm <= 0 || a.gn <= 0 || a.grid <= 0) return hipErrorInvalidValue;
     switch (dtype) {
         case DT_F32: return launch_mode<TF32>(mode, nt, a, s);
         case DT_BF16: return launch_mode<TBF16>(mode, nt, a, s);
