@@ -82,6 +82,19 @@ def host_cores() -> int:
     return max(1, n)
 
 
+def traffic_from_profile(args, per_gpu):
+    """HBM-side bytes per 3x3-kernel launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic_conv3w.json:
+    FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate passes, same command with a 3-image micro-batch).
+    PMC counters cannot be collected from inside this process, so the figure is only quoted for the profiled workload."""
+    path = REPO / "profiles" / "r01_pmc_traffic_conv3w.json"
+    if args.workload != "cfg3_1080p" or args.dtype != "bf16" or not path.exists():
+        return None
+    try:
+        return json.loads(path.read_text())["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(cfg, sd, model, dtype, sample_hw):
     """Times the CPU oracle on a bounded sample and checks the GPU result against it."""
     from oracle import mewzoom_oracle as oracle  # checker / baseline only
@@ -137,10 +150,17 @@ def main():
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; MZ_BENCH_BACKEND=gloo lets several ranks share one GPU for plumbing rehearsals on a 1-GPU box
+    backend = os.environ.get("MZ_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, ndev)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     model_name, per_gpu, H, W, desc = WORKLOADS[args.workload]
     if args.images_per_gpu > 0:
@@ -231,7 +251,7 @@ def main():
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": conv_tflops / peak,
-                "traffic": None,
+                "traffic": traffic_from_profile(args, per_gpu),
                 "launches": prof["conv_launches"],
                 "avg_launch_ms": prof["conv_ms"] / max(1.0, prof["conv_launches"]),
                 "algorithmic_tflop_per_step": prof["conv_flops"] / 1e12,

@@ -43,11 +43,21 @@ def gather_outputs(local: Tensor, batch: int, dst: int = 0, group=None) -> Optio
         pad = torch.zeros((longest - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         send = torch.cat([local, pad], dim=0)
     send = send.contiguous()
+    # gloo cannot gather device tensors: stage through host memory (rehearsals only; RCCL gathers in HBM)
+    via_host = send.is_cuda and dist.get_backend(group) == "gloo"
+    wire = send.cpu() if via_host else send
     if rank == dst:
-        bufs = [torch.empty_like(send) for _ in range(world)]
-        dist.gather(send, gather_list=bufs, dst=dst, group=group)
-        return torch.cat([b[:n] for b, n in zip(bufs, sizes)], dim=0)
-    dist.gather(send, gather_list=None, dst=dst, group=group)
+        if len(set(sizes)) == 1:
+            # equal slices: receive straight into the final tensor, no second copy
+            full = torch.empty((batch,) + tuple(wire.shape[1:]), dtype=wire.dtype, device=wire.device)
+            bufs = [full[i * longest : (i + 1) * longest] for i in range(world)]
+            dist.gather(wire, gather_list=bufs, dst=dst, group=group)
+        else:
+            bufs = [torch.empty_like(wire) for _ in range(world)]
+            dist.gather(wire, gather_list=bufs, dst=dst, group=group)
+            full = torch.cat([b[:n] for b, n in zip(bufs, sizes)], dim=0)
+        return full.to(local.device) if via_host else full
+    dist.gather(wire, gather_list=None, dst=dst, group=group)
     return None
 
 
