@@ -104,6 +104,13 @@ int mz_workspace_bytes(const mz_handle* h, int B, int H, int W, int max_images_i
 int mz_forward(mz_handle* h, const void* x, void* out_sr, float* out_qa, int B, int H, int W, int clamp,
                void* workspace, size_t workspace_bytes, int max_images_in_flight, void* hip_stream);
 
+/* The same path with uint8 images at both ends: every caller of the reference wraps
+ * upscale() in `ToDtype(float32, scale=True)` and `save_image` (README.md:72-83, test_compare.py:53-57,89); here the
+ * /255 happens in the stem's read and clamp -> *255 + 0.5 -> uint8 in the final store, so the two extra passes over
+ * the largest tensors disappear.   x [B,3,H,W] uint8 -> out_sr [B,3,rH,rW] uint8. */
+int mz_forward_u8(mz_handle* h, const uint8_t* x, uint8_t* out_sr, float* out_qa, int B, int H, int W,
+                  void* workspace, size_t workspace_bytes, int max_images_in_flight, void* hip_stream);
+
 /* ---- single operators, exported for the parity tests (tests/test_ops_gpu.py) ---------------
  * These run the SAME kernels mz_forward launches, on caller-provided tensors.
  * Activation tensors here are the library's internal layout: plane-major [B][P][H][W][16 bytes], channel count padded

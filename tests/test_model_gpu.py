@@ -166,3 +166,26 @@ def test_cfg5_substitute_4k_single_image_fp16():
     print(f"cfg5-substitute 4K fp16: max-abs {err:.3e} PSNR {p:.1f} dB (crop check)")
     assert p >= 70.0 and err <= 4e-3
     assert torch.equal(m.upscale(x.to("cuda", torch.float16)), full)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_uint8_io_matches_float_path_with_save_image_rounding(dtype):
+    """uint8 in / uint8 out equals round-half-up(255 * upscale(x / 255)) of the float path."""
+    case = GoldenCase("g9_4x_c32")
+    m = build(case, case.weights(), dtype)
+    xu = (synth_image(2, 40, 56, 91) * 255).round().to(torch.uint8)
+    got = m.upscale_uint8(xu.cuda())
+    assert got.dtype == torch.uint8 and got.shape == (2, 3, 160, 224)
+    with torch.inference_mode():
+        want = oracle.upscale(case.config, case.weights(), xu.float() / 255)
+    want_u8 = (want * 255 + 0.5).clamp(0, 255).to(torch.uint8)
+    diff = (got.cpu().int() - want_u8.int()).abs()
+    print(f"uint8 I/O {dtype}: max LSB diff {diff.max().item()}, mismatching {100.0 * (diff > 0).float().mean().item():.3f} %")
+    if dtype == torch.float32:
+        assert diff.max().item() <= 1 and (diff > 0).float().mean().item() < 1e-3  # only exact .5 ties may flip
+    else:
+        assert diff.max().item() <= 3
+    # and bit-for-bit against this library's own float path fed the same pixels
+    y = m.upscale((xu.float() / 255).to("cuda", dtype)).float()
+    if dtype == torch.float32:
+        assert torch.equal(got.cpu(), (y * 255 + 0.5).clamp(0, 255).to(torch.uint8).cpu())

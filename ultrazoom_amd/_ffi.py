@@ -55,6 +55,8 @@ def _declare(lib) -> None:
     lib.mz_weights_complete.argtypes = [H]
     lib.mz_workspace_bytes.argtypes = [H, c_int, c_int, c_int, c_int, POINTER(c_size_t)]
     lib.mz_forward.argtypes = [H, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_int, c_void_p]
+    lib.mz_forward_u8.argtypes = [H, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_int, c_void_p]
+    lib.mz_forward_u8.restype = c_int
     lib.mz_padded_channels.argtypes = [c_int]
     lib.mz_op_conv.argtypes = [c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p] + [c_int] * 8 + [c_void_p]
     lib.mz_op_stem.argtypes = [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
@@ -154,6 +156,14 @@ class Handle:
         check(
             lib().mz_forward(
                 self._h, c_void_p(x_ptr), c_void_p(sr_ptr), c_void_p(qa_ptr) if qa_ptr else None, B, H, W, int(clamp),
+                c_void_p(ws_ptr), ws_bytes, max_in_flight, c_void_p(stream),
+            )
+        )
+
+    def forward_u8(self, x_ptr, sr_ptr, qa_ptr, B, H, W, ws_ptr, ws_bytes, max_in_flight, stream) -> None:
+        check(
+            lib().mz_forward_u8(
+                self._h, c_void_p(x_ptr), c_void_p(sr_ptr), c_void_p(qa_ptr) if qa_ptr else None, B, H, W,
                 c_void_p(ws_ptr), ws_bytes, max_in_flight, c_void_p(stream),
             )
         )

@@ -500,6 +500,7 @@ struct Runner {
     int rc = MZ_OK;
     bool wide_tiles = getenv("MZ_NO_WIDE") == nullptr;  // MZ_NO_WIDE=1 forces the 256-pixel kernel (A/B timing)
     bool no_fuse = getenv("MZ_NO_FUSE") != nullptr;     // MZ_NO_FUSE=1 keeps conv2 and the mix as two launches
+    int io_u8 = 0;                                        // images at both ends are uint8 (mz_forward_u8)
 
     void prof_begin(ProfRec*& r, double flops, double bytes, int is_conv3) {
         r = nullptr;
@@ -583,7 +584,7 @@ struct Runner {
         a.p_out = a.cp_out * dtype_size(dtype) / 16;
         a.Hout = Hout; a.Wout = Wout;
         a.img = img; a.R = R; a.clamp = clamp;
-        if (epi == EPI_FINAL) { a.Hi = Hout / R; a.Wi = Wout / R; }
+        if (epi == EPI_FINAL) { a.Hi = Hout / R; a.Wi = Wout / R; a.io_u8 = io_u8; }
         double extra_flops = 0.0;
         if (epi == EPI_FUSEDMIX) {
             a.in1 = xin;
@@ -664,10 +665,11 @@ struct Runner {
 // forward
 // ------------------------------------------------------------------------------------------------
 static int forward_micro(mz_handle* h, const char* x, char* out_sr, float* out_qa, int nb, int H, int W, int clamp,
-                         char* ws, hipStream_t s) {
+                         char* ws, hipStream_t s, int io_u8) {
     Plan p;
     make_plan(h, nb, H, W, p);
     Runner run{h, s, h->dtype};
+    run.io_u8 = io_u8;
     const int r = h->cfg.upscale_ratio;
 
     auto block = [&](const BlockW& b, const void* xin, void* hid, void* z, void* yout, int hh, int ww) {
@@ -684,7 +686,7 @@ static int forward_micro(mz_handle* h, const char* x, char* out_sr, float* out_q
 
     // stem (model.py:158): NCHW image -> NHWC features
     char* cur = ws + p.R[0][0];
-    if (hipError_t e = launch_stem(h->dtype, x, h->stem_w4, cur, nb, H, W, pad16(h->ch[0]), s); e != hipSuccess)
+    if (hipError_t e = launch_stem(h->dtype, x, h->stem_w4, cur, nb, H, W, pad16(h->ch[0]), s, io_u8); e != hipSuccess)
         return fail(MZ_ERR_HIP, "stem launch: %s", hipGetErrorString(e));
 
     // encoder (model.py:461-484)
@@ -771,8 +773,8 @@ static int forward_micro(mz_handle* h, const char* x, char* out_sr, float* out_q
     return run.rc;
 }
 
-extern "C" int mz_forward(mz_handle* h, const void* x, void* out_sr, float* out_qa, int B, int H, int W, int clamp,
-                          void* workspace, size_t workspace_bytes, int max_images_in_flight, void* hip_stream) {
+static int forward_impl(mz_handle* h, const void* x, void* out_sr, float* out_qa, int B, int H, int W, int clamp,
+                        void* workspace, size_t workspace_bytes, int max_images_in_flight, void* hip_stream, int io_u8) {
     if (!h || !x || !out_sr || !workspace) return fail(MZ_ERR_INVALID_ARGUMENT, "null argument");
     if (B <= 0 || H < 8 || W < 8) return fail(MZ_ERR_INVALID_ARGUMENT, "need B >= 1 and H, W >= 8 (got %d, %d, %d)", B, H, W);
     int rc = mz_weights_complete(h);
@@ -782,7 +784,7 @@ extern "C" int mz_forward(mz_handle* h, const void* x, void* out_sr, float* out_
     make_plan(h, nbmax, H, W, p);
     if (workspace_bytes < p.total)
         return fail(MZ_ERR_WORKSPACE_TOO_SMALL, "workspace too small: %zu bytes given, %zu needed", workspace_bytes, p.total);
-    const size_t sz = dtype_size(h->dtype);
+    const size_t sz = io_u8 ? 1 : dtype_size(h->dtype);
     const int r = h->cfg.upscale_ratio;
     const size_t in_img = (size_t)3 * H * W * sz;
     const size_t out_img = (size_t)3 * H * r * W * r * sz;
@@ -790,10 +792,21 @@ extern "C" int mz_forward(mz_handle* h, const void* x, void* out_sr, float* out_
         const int nb = std::min(nbmax, B - b0);
         rc = forward_micro(h, (const char*)x + b0 * in_img, (char*)out_sr + b0 * out_img,
                            out_qa ? out_qa + (size_t)b0 * h->cfg.num_deg_features : nullptr, nb, H, W, clamp,
-                           (char*)workspace, (hipStream_t)hip_stream);
+                           (char*)workspace, (hipStream_t)hip_stream, io_u8);
         if (rc) return rc;
     }
     return MZ_OK;
+}
+
+extern "C" int mz_forward(mz_handle* h, const void* x, void* out_sr, float* out_qa, int B, int H, int W, int clamp,
+                          void* workspace, size_t workspace_bytes, int max_images_in_flight, void* hip_stream) {
+    return forward_impl(h, x, out_sr, out_qa, B, H, W, clamp, workspace, workspace_bytes, max_images_in_flight, hip_stream, 0);
+}
+
+extern "C" int mz_forward_u8(mz_handle* h, const uint8_t* x, uint8_t* out_sr, float* out_qa, int B, int H, int W,
+                             void* workspace, size_t workspace_bytes, int max_images_in_flight, void* hip_stream) {
+    return forward_impl(h, x, out_sr, out_qa, B, H, W, /*clamp (implied by the uint8 store)*/ 1, workspace, workspace_bytes,
+                        max_images_in_flight, hip_stream, 1);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -61,6 +61,7 @@ struct ConvArgs {
     int R;             // FINAL: total upscale ratio of img -> out
     int Hi, Wi;        // FINAL: img size
     int clamp;
+    int io_u8;         // EPI_FINAL: img and out are uint8 images (scaled by 1/255 on read, x255 + 0.5 on write)
     int use_glds;      // stage through global_load_lds (1) or through registers (0)
     unsigned long long* dbg;  // -DMZ_STAMP diagnostic builds: per-stage s_memtime stamps of one workgroup
 };
@@ -92,7 +93,7 @@ hipError_t launch_pack(const PackArgs& a, hipStream_t s);
 // stem weights: float [cp][4] = {w0, w1, w2, bias}
 hipError_t launch_pack_stem(const float* w, const float* b, float* dst, int c, int cp, hipStream_t s);
 hipError_t launch_stem(int dtype, const void* x, const float* w4, void* out, int B, int H, int W, int cp,
-                       hipStream_t s);
+                       hipStream_t s, int u8 = 0);
 // zero rows >= Hv and columns >= Wv of an NHWC tensor [B,Hout,Wout,cp]
 hipError_t launch_zero_border(int dtype, void* t, int B, int Hout, int Wout, int cp, int Hv, int Wv,
                               hipStream_t s);

@@ -58,6 +58,18 @@ template <> __device__ __forceinline__ void st1<TF32>(void* p, float v) { *(floa
 template <> __device__ __forceinline__ void st1<TBF16>(void* p, float v) { *(__bf16*)p = (__bf16)v; }
 template <> __device__ __forceinline__ void st1<TF16>(void* p, float v) { *(_Float16*)p = (_Float16)v; }
 
+// image pixels at the two ends of the path: the module dtype, or uint8 with the scaling every caller of the reference
+// applies around upscale() (torchvision ToDtype(scale=True) before, save_image's mul(255).add(0.5).clamp().byte() after;
+// reference README.md:72-83, test_compare.py:53-57,89)
+template <class TT> __device__ __forceinline__ float ld_img(const void* base, long long idx, int u8) {
+    if (u8) return (float)((const uint8_t*)base)[idx] / 255.0f;  // a true division, as ToDtype(scale=True) does
+    return ld1<TT>((const char*)base + idx * TT::SZ);
+}
+template <class TT> __device__ __forceinline__ void st_img(void* base, long long idx, float v, int u8) {
+    if (u8) ((uint8_t*)base)[idx] = (uint8_t)fminf(fmaxf(v * 255.0f + 0.5f, 0.0f), 255.0f);
+    else st1<TT>((char*)base + idx * TT::SZ, v);
+}
+
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
     uint16_t lo = __builtin_bit_cast(uint16_t, (__bf16)a);
     uint16_t hi = __builtin_bit_cast(uint16_t, (__bf16)b);
@@ -362,18 +374,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const int epi, 
                         for (int i = 0; i < 4; ++i) rowy[i] = min(max(ky + fy - 1 + i, 0), a.Hi - 1);
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
-                            const char* ip = (const char*)a.img + ((long long)b * 3 + c) * plane_i * SZ;
+                            const long long ip = ((long long)b * 3 + c) * plane_i;
                             float sres = 0.0f;
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
-                                const char* rp = ip + (long long)rowy[i] * a.Wi * SZ;
-                                const float rowv = ld1<TT>(rp + colx[0] * SZ) * cx[0] + ld1<TT>(rp + colx[1] * SZ) * cx[1] +
-                                                   ld1<TT>(rp + colx[2] * SZ) * cx[2] + ld1<TT>(rp + colx[3] * SZ) * cx[3];
+                                const long long rp = ip + (long long)rowy[i] * a.Wi;
+                                const float rowv = ld_img<TT>(a.img, rp + colx[0], a.io_u8) * cx[0] + ld_img<TT>(a.img, rp + colx[1], a.io_u8) * cx[1] +
+                                                   ld_img<TT>(a.img, rp + colx[2], a.io_u8) * cx[2] + ld_img<TT>(a.img, rp + colx[3], a.io_u8) * cx[3];
                                 sres += rowv * cy[i];
                             }
                             float v = sres + *(const float*)(ep + px * ROWF + ((2 * i2 + jj) * 4 + c) * 4);
                             if (a.clamp) v = fminf(fmaxf(v, 0.0f), 1.0f);
-                            st1<TT>((char*)a.out + ((((long long)b * 3 + c) * plane_o) + (long long)Y * a.Wout + X) * SZ, v);
+                            st_img<TT>(a.out, (((long long)b * 3 + c) * plane_o) + (long long)Y * a.Wout + X, v, a.io_u8);
                         }
                     }
                 }
@@ -1237,7 +1249,7 @@ hipError_t launch_pack_stem(const float* w, const float* b, float* dst, int c, i
 
 // FanOutProjection (reference model.py:239-242): per-pixel 3 -> C affine, NCHW image -> plane-major features.
 template <class TT> __global__ void stem_kernel(const void* x, const float4* w4, void* out, long long total, long long HW,
-                                                int groups) {
+                                                int groups, int u8) {
     constexpr int SZ = TT::SZ;
     constexpr int NPL = SZ / 2;  // planes per group of 8 channels
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1246,8 +1258,8 @@ template <class TT> __global__ void stem_kernel(const void* x, const float4* w4,
     const long long t = idx / HW;
     const int g = (int)(t % groups);
     const long long b = t / groups;
-    const char* xp = (const char*)x + (b * 3 * HW + p) * SZ;
-    const float r0 = ld1<TT>(xp), r1 = ld1<TT>(xp + HW * SZ), r2 = ld1<TT>(xp + 2 * HW * SZ);
+    const long long xi = b * 3 * HW + p;
+    const float r0 = ld_img<TT>(x, xi, u8), r1 = ld_img<TT>(x, xi + HW, u8), r2 = ld_img<TT>(x, xi + 2 * HW, u8);
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -1263,15 +1275,16 @@ template <class TT> __global__ void stem_kernel(const void* x, const float4* w4,
         st4<TT>(op + HW * 16, v + 4);
     }
 }
-hipError_t launch_stem(int dtype, const void* x, const float* w4, void* out, int B, int H, int W, int cp, hipStream_t s) {
+hipError_t launch_stem(int dtype, const void* x, const float* w4, void* out, int B, int H, int W, int cp, hipStream_t s,
+                       int u8) {
     const long long HW = (long long)H * W;
     const int groups = cp / 8;
     const long long total = HW * B * groups;
     const int blocks = (int)((total + 255) / 256);
     switch (dtype) {
-        case DT_F32: hipLaunchKernelGGL(stem_kernel<TF32>, dim3(blocks), dim3(256), 0, s, x, (const float4*)w4, out, total, HW, groups); break;
-        case DT_BF16: hipLaunchKernelGGL(stem_kernel<TBF16>, dim3(blocks), dim3(256), 0, s, x, (const float4*)w4, out, total, HW, groups); break;
-        case DT_F16: hipLaunchKernelGGL(stem_kernel<TF16>, dim3(blocks), dim3(256), 0, s, x, (const float4*)w4, out, total, HW, groups); break;
+        case DT_F32: hipLaunchKernelGGL(stem_kernel<TF32>, dim3(blocks), dim3(256), 0, s, x, (const float4*)w4, out, total, HW, groups, u8); break;
+        case DT_BF16: hipLaunchKernelGGL(stem_kernel<TBF16>, dim3(blocks), dim3(256), 0, s, x, (const float4*)w4, out, total, HW, groups, u8); break;
+        case DT_F16: hipLaunchKernelGGL(stem_kernel<TF16>, dim3(blocks), dim3(256), 0, s, x, (const float4*)w4, out, total, HW, groups, u8); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -241,6 +241,20 @@ class MewZoom(nn.Module, PyTorchModelHubMixin):
         _, qa = self._run(x, clamp=False, want_qa=True)
         return qa.to(x.dtype)
 
+    @torch.inference_mode()
+    def upscale_uint8(self, x: Tensor) -> Tensor:
+        """uint8 in, uint8 out: ``save_image``-style rounding of ``upscale(x / 255)``.
+
+        What every caller of the reference does around ``upscale`` (``ToDtype(float32, scale=True)`` before,
+        ``save_image`` after; README.md:72-83, test_compare.py:53-57,89), with both conversions fused into the first
+        and last kernels."""
+        assert x.dim() == 4 and x.shape[1] == 3 and x.dtype == torch.uint8, "expected a (B, 3, H, W) uint8 tensor"
+        if not x.is_cuda:
+            raise RuntimeError("ultrazoom_amd.MewZoom computes on an MI355X only: move the input to a 'cuda' device.")
+        p0 = next(self.parameters())
+        engine = self._get_engine(torch.empty(0, dtype=p0.dtype, device=x.device))
+        return engine.run_u8(x.contiguous(), self.max_images_in_flight)
+
     # ---- checkpoint ingestion (test_compare.py:32-45 of the reference) -------------------------
     def load_training_checkpoint(self, state_dict: Dict[str, Tensor]) -> None:
         """Loads a raw training checkpoint: strips ``_orig_mod.`` prefixes left by torch.compile and
@@ -317,3 +331,17 @@ class _Engine:
                 self._workspace.data_ptr(), self._workspace.numel(), max_in_flight, stream,
             )
         return sr, qa
+
+    def run_u8(self, x: Tensor, max_in_flight: int) -> Tensor:
+        B, _, H, W = x.shape
+        r = self.config["upscale_ratio"]
+        with torch.cuda.device(self.device):
+            need = self.handle.workspace_bytes(B, H, W, max_in_flight)
+            if self._workspace is None or self._workspace.numel() < need:
+                self._workspace = None
+                self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+            sr = torch.empty((B, 3, H * r, W * r), dtype=torch.uint8, device=self.device)
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            self.handle.forward_u8(x.data_ptr(), sr.data_ptr(), 0, B, H, W, self._workspace.data_ptr(),
+                                   self._workspace.numel(), max_in_flight, stream)
+        return sr
