@@ -94,7 +94,10 @@ static void plan_conv(ConvW& c, int dtype, int mode, int cout, int cin, int kh, 
         c.nchunks = 4 * c.cp0 / ck;
     }
     c.nchunks_real = c.nchunks;
-    if (mode == MODE_GEMM1) c.nchunks = (c.nchunks + 2) / 3 * 3;  // the 1x1 kernel consumes 3 chunks per stage
+    if (mode == MODE_GEMM1) {  // the 1x1 kernel consumes S chunks per stage: pad K with zero weights
+        const int S = gemm1_chunks_per_stage();
+        c.nchunks = (c.nchunks + S - 1) / S * S;
+    }
     c.packed_sz = packed_bytes(c.taps, c.nt, c.ntiles, c.nchunks);
 }
 

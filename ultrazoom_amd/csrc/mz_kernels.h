@@ -44,7 +44,7 @@ struct ConvArgs {
     int Ho, Wo;        // output pixel grid of the GEMM (== H,W for CONV3; H/2,W/2 for CRUSH)
     int p0, p1;        // planes (16-byte channel groups) of in0 / in1: padded_channels * sizeof / 16
     int p_out;         // planes of the output tensor (D2S: of the shuffled target)
-    int nchunks;       // K chunks in total (GEMM1: padded to a multiple of 3 with zero weights)
+    int nchunks;       // K chunks in total (GEMM1: padded to a whole number of stages with zero weights)
     int nchunks_real;  // chunks that exist in the sources
     int nchunks0;      // CONCAT: chunks that come from in0; CRUSH: chunks per tap
     int src;           // SrcKind
@@ -69,6 +69,7 @@ struct ConvArgs {
 size_t conv_lds_bytes(int mode, int nt);
 // picks NT (32*NT output channels per workgroup) for a logical padded N
 int choose_nt(int n_padded);
+int gemm1_chunks_per_stage();
 hipError_t launch_conv(int dtype, int mode, int nt, const ConvArgs& a, hipStream_t s);
 hipError_t init_kernels();  // raises the dynamic-LDS limits once per process
 

@@ -202,6 +202,9 @@ static constexpr bool kGlds = true;
 #ifndef MZ_ABLATE
 #define MZ_ABLATE 0
 #endif
+#ifndef MZ_GEMM1_S
+#define MZ_GEMM1_S 2  // K-chunks per stage of the 1x1 kernel: 44 KiB of LDS -> 3 workgroups per CU (measured best of 1..4)
+#endif
 template <int MODE> struct Geo;
 template <> struct Geo<MODE_CONV3> {  // 4 waves, 8 x 32 pixels
     static constexpr int TAPS = 9;
@@ -213,9 +216,9 @@ template <> struct Geo<MODE_CONV3> {  // 4 waves, 8 x 32 pixels
 };
 template <> struct Geo<MODE_GEMM1> {
     static constexpr int TAPS = 1;
-    static constexpr int S = 3;
+    static constexpr int S = MZ_GEMM1_S;
     static constexpr int ROWW = 0;
-    static constexpr int A_ENT = 3 * 512;
+    static constexpr int A_ENT = MZ_GEMM1_S * 512;
     static constexpr int PLANE = 256 * 16;
     static constexpr int MF_STRIDE = 32 * 16;
 };
@@ -1045,12 +1048,14 @@ size_t conv_lds_bytes(int mode, int nt) {
         return ring > epi ? ring : epi;
     }
     const int taps = mode == MODE_CONV3 ? 9 : 1;
-    const int S = mode == MODE_CONV3 ? 1 : 3;
-    const int a_bytes = (mode == MODE_CONV3 ? 704 : 3 * 512) * 16;
+    const int S = mode == MODE_CONV3 ? 1 : MZ_GEMM1_S;
+    const int a_bytes = (mode == MODE_CONV3 ? 704 : MZ_GEMM1_S * 512) * 16;
     const size_t staging = 2 * (size_t)(a_bytes + taps * S * nt * 1024);
     const size_t epi = 4 * 32 * (size_t)(32 * nt * 4 + 16);
     return staging > epi ? staging : epi;
 }
+
+int gemm1_chunks_per_stage() { return MZ_GEMM1_S; }
 
 int choose_nt(int n_padded) {
     // smallest padded N wins; ties prefer 3, 2, 4, 1 (4 needs 94 KiB of LDS: one workgroup per CU)
