@@ -68,3 +68,23 @@ def test_unknown_weight_and_missing_weights_fail_loudly():
         h.weights_complete()
     assert "has not been set" in str(ei.value)
     h.close()
+
+
+def test_weights_cannot_be_set_without_a_gpu():
+    """No silent fallback: on a machine without an MI355X the library refuses instead of computing somewhere else."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("this check is for GPU-less machines")
+    case = GoldenCase("g1_2x_c16")
+    h = _ffi.Handle(case.config, _ffi.MZ_F32)
+    with pytest.raises(_ffi.MewZoomHipError) as ei:
+        h.set_weight("stem.conv.bias", 0x1000, (16,), 0)
+    assert ei.value.code in (-7, -6)  # MZ_ERR_NO_DEVICE / MZ_ERR_HIP
+    with pytest.raises(_ffi.MewZoomHipError) as ei:
+        h.set_weight("no.such.parameter", 0x1000, (16,), 0)
+    assert ei.value.code == -2
+    with pytest.raises(_ffi.MewZoomHipError) as ei:
+        h.set_weight("stem.conv.bias", 0x1000, (17,), 0)
+    assert ei.value.code == -3
+    h.close()
