@@ -27,6 +27,10 @@ for i in range(60):
         vals.append((t1_ - t0_) / (r1_ - r0_) * 100.0)
 if vals:
     print(f"in-kernel clock over the K loop (MHz): median {np.median(vals):.0f} min {min(vals):.0f} max {max(vals):.0f} n={len(vals)}; K-loop cycles median {np.median([c[2]-c[0] for c in clk[:60] if c[3]>c[1]>0]):.0f}")
+ph = [(c[0] - c[5], c[2] - c[0], c[4] - c[2]) for c in clk[:60] if c[3] > c[1] > 0 and c[5] > 0 and c[4] > 0]
+if ph:
+    arr = np.array(ph)
+    print(f"per-workgroup phases (cycles, median): entry->K-loop {np.median(arr[:,0]):.0f} | K-loop {np.median(arr[:,1]):.0f} | epilogue {np.median(arr[:,2]):.0f}")
 if os.environ.get("CLOCK_ONLY"): sys.exit(0)
 nst = min(cin // 16, 64)
 t0 = a[0, 0, 0]

@@ -398,6 +398,73 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const int epi, 
         return;
     }
 
+    if (!IS_CONV) {
+        // 1x1 kernels (residual mix, PixelCrush).
+        // Direct stores.  An accumulator quad = 4 consecutive channels of the lane's pixel = half (16-bit types) or all (f32)
+        // of one 16-byte plane entry; lanes (h, r) and (1-h, r) hold the two halves, and r walks 32 consecutive pixels, so
+        // one store instruction covers 512 contiguous bytes of a plane: no LDS transpose is needed in the plane-major layout.
+        constexpr int PPU = SZ == 2 ? 8 : 4;  // channels per plane
+        const long long hwo = (long long)a.Ho * a.Wo;
+        const long long M = (long long)a.B * hwo;
+    #pragma unroll
+        for (int mf = 0; mf < 2; ++mf) {
+            int bimg = -1;       // image index, -1 = pixel outside the tensor
+            long long pix = 0;   // y * Wo + x inside the image
+            int py = 0, pxx = 0;
+            if (IS_CONV) {
+                py = ey[mf];
+                pxx = ex[mf] + r;
+                if (py < a.H && pxx < a.W) {
+                    bimg = b;
+                    pix = (long long)py * a.W + pxx;
+                }
+            } else {
+                const long long m = em[mf] + r;
+                if (m < M) {
+                    bimg = (int)(m / hwo);
+                    pix = m - (long long)bimg * hwo;
+                }
+            }
+            if (bimg < 0) continue;
+            const long long plane_o = (IS_CONV && epi == EPI_D2S) ? (long long)a.Hout * a.Wout * 16 : hwo * 16;
+            char* const obase = (char*)a.out + (long long)bimg * a.p_out * plane_o;
+    #pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+    #pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[4];
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[mf][nt][4 * q + j];
+                    const int n = nbase + 32 * nt + 8 * q + 4 * h;
+                    if (silu) {
+    #pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = v[j] * sigmoidf_(v[j]);
+                    }
+                    if (IS_CONV && epi == EPI_D2S) {
+                        if (n < 4 * a.cp_out) {
+                            const int ij = n / a.cp_out;
+                            const int c = n - ij * a.cp_out;
+                            const int Y = 2 * py + (ij >> 1), X = 2 * pxx + (ij & 1);
+                            const int plane = c / PPU, inner = (c - plane * PPU) * SZ;
+                            st4<TT>(obase + plane * plane_o + ((long long)Y * a.Wout + X) * 16 + inner, v);
+                        }
+                    } else if (n < a.cp_out) {
+                        const int plane = n / PPU, inner = (n - plane * PPU) * SZ;
+                        if (epi == EPI_MIX) {
+                            float xv[4], zv[4];
+                            ld4<TT>((const char*)a.in0 + (((long long)bimg * a.p0 + plane) * hwo + pix) * 16 + inner, xv);
+                            ld4<TT>((const char*)a.in1 + (((long long)bimg * a.p1 + plane) * hwo + pix) * 16 + inner, zv);
+    #pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = xv[j] + a.mix_scale * sigmoidf_(v[j]) * (zv[j] - xv[j]);
+                        }
+                        st4<TT>(obase + plane * plane_o + pix * 16 + inner, v);
+                    }
+                }
+            }
+        }
+        return;
+    }
+
     constexpr int ROWB = BN * SZ + 16;
     constexpr int UPP = BN * SZ / 16;  // 16-byte units per pixel row
     constexpr int UPW = UPP / 2;       // units per lane (32 pixels * UPP / 64 lanes)
