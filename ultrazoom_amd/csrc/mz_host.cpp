@@ -558,6 +558,12 @@ struct Runner {
         a.gm = best_gm; a.gn = best_gn;
         const long long groups = (long long)((a.mtiles + a.gm - 1) / a.gm) * ((a.ntiles + a.gn - 1) / a.gn);
         a.grid = (int)(groups * a.gm * a.gn);
+        a.groups_m = (a.mtiles + a.gm - 1) / a.gm;
+        a.inv_gsz = 1.0f / (float)(a.gm * a.gn);
+        a.inv_groups_m = 1.0f / (float)a.groups_m;
+        a.inv_gn = 1.0f / (float)a.gn;
+        a.inv_tpi = a.tiles_x > 0 ? 1.0f / (float)(a.tiles_x * a.tiles_y) : 1.0f;
+        a.inv_tiles_x = a.tiles_x > 0 ? 1.0f / (float)a.tiles_x : 1.0f;
     }
 
     // conv3x3, pad 1 (model.py:742-748, 900-909, 1010). epi: STORE / D2S / FINAL

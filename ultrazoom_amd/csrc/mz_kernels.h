@@ -53,6 +53,8 @@ struct ConvArgs {
     int tiles_x, tiles_y;  // CONV3: tiles per image
     int gm, gn;        // tile-group shape of the workgroup -> tile walk (map_tile)
     int grid;          // workgroups launched: whole groups, >= mtiles * ntiles
+    int groups_m;      // ceil(mtiles / gm)
+    float inv_gsz, inv_groups_m, inv_gn, inv_tpi, inv_tiles_x;  // 1.0f / divisor for fdiv() (all dividends < 2^24)
     int epi;
     int silu;
     int cp_out;        // STORE/MIX: padded channels of out; D2S: channels per output pixel (cq_p)

@@ -306,16 +306,24 @@ __device__ __forceinline__ void run_items(f32x16 (&acc)[2][NT], Frags<NT>& cur, 
 // resident on an XCD together then share gm activation tiles and gn weight tiles through that XCD's L2 instead of
 // re-streaming one operand per tile of the other.  Returns false for the padding ids of a partial group.
 // ================================================================================================
+// x / d for 0 <= x < 2^24 with a host-provided 1.0f / d: a handful of instructions instead of the ~30 of a runtime
+// integer division (the tile bookkeeping below ran five of them per workgroup)
+__device__ __forceinline__ int fdiv(int x, int d, float inv) {
+    int q = (int)((float)x * inv);
+    const int r = x - q * d;
+    q += (r >= d) - (r < 0);
+    return q;
+}
+
 __device__ __forceinline__ bool map_tile(const ConvArgs& a, int& mtile, int& ntile) {
     const int nblk = gridDim.x;
     const int bid = blockIdx.x;
     const int q = nblk >> 3, rem = nblk & 7, xcd = bid & 7, pos = bid >> 3;
     const int L = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + pos;
     const int gsz = a.gm * a.gn;
-    const int group = L / gsz, within = L - group * gsz;
-    const int groups_m = (a.mtiles + a.gm - 1) / a.gm;
-    const int gi_n = group / groups_m, gi_m = group - gi_n * groups_m;
-    const int mi = within / a.gn, ni = within - mi * a.gn;
+    const int group = fdiv(L, gsz, a.inv_gsz), within = L - group * gsz;
+    const int gi_n = fdiv(group, a.groups_m, a.inv_groups_m), gi_m = group - gi_n * a.groups_m;
+    const int mi = fdiv(within, a.gn, a.inv_gn), ni = within - mi * a.gn;
     mtile = gi_m * a.gm + mi;
     ntile = gi_n * a.gn + ni;
     return mtile < a.mtiles && ntile < a.ntiles;
@@ -687,9 +695,9 @@ __global__ __launch_bounds__(576, 3) void conv3w_kernel(const ConvArgs a) {
 
     // ------------------------- compute waves -------------------------
     const int tpi = a.tiles_x * a.tiles_y;
-    const int b = mtile / tpi;
+    const int b = fdiv(mtile, tpi, a.inv_tpi);
     const int trem = mtile - b * tpi;
-    const int tyi = trem / a.tiles_x;
+    const int tyi = fdiv(trem, a.tiles_x, a.inv_tiles_x);
     const int y0 = tyi * G::TH;
     const int x0 = (trem - tyi * a.tiles_x) * G::TW;
 
@@ -962,9 +970,9 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
     const long long M = (long long)a.B * a.Ho * a.Wo;
     if (MODE == MODE_CONV3) {
         const int tpi = a.tiles_x * a.tiles_y;
-        b = mtile / tpi;
+        b = fdiv(mtile, tpi, a.inv_tpi);
         const int rem = mtile - b * tpi;
-        const int ty = rem / a.tiles_x;
+        const int ty = fdiv(rem, a.tiles_x, a.inv_tiles_x);
         y0 = ty * 8;
         x0 = (rem - ty * a.tiles_x) * 32;
     } else {
@@ -1175,6 +1183,7 @@ template <class TT> static hipError_t launch_mode(int mode, int nt, const ConvAr
 }
 hipError_t launch_conv(int dtype, int mode, int nt, const ConvArgs& a, hipStream_t s) {
     if (a.mtiles <= 0 || a.ntiles <= 0 || a.gm <= 0 || a.gn <= 0 || a.grid <= 0) return hipErrorInvalidValue;
+    if (a.grid >= (1 << 24)) return hipErrorInvalidValue;  // fdiv() needs dividends below 2^24
     switch (dtype) {
         case DT_F32: return launch_mode<TF32>(mode, nt, a, s);
         case DT_BF16: return launch_mode<TBF16>(mode, nt, a, s);
