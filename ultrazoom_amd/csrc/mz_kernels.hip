@@ -61,12 +61,12 @@ template <> __device__ __forceinline__ void st1<TF16>(void* p, float v) { *(_Flo
 // image pixels at the two ends of the path: the module dtype, or uint8 with the scaling every caller of the reference
 // applies around upscale() (torchvision ToDtype(scale=True) before, save_image's mul(255).add(0.5).clamp().byte() after;
 // reference README.md:72-83, test_compare.py:53-57,89)
-template <class TT> __device__ __forceinline__ float ld_img(const void* base, long long idx, int u8) {
-    if (u8) return (float)((const uint8_t*)base)[idx] / 255.0f;  // a true division, as ToDtype(scale=True) does
-    return ld1<TT>((const char*)base + idx * TT::SZ);
+template <class TT, bool U8> __device__ __forceinline__ float ld_img(const void* base, long long idx) {
+    if constexpr (U8) return (float)((const uint8_t*)base)[idx] / 255.0f;  // a true division, as ToDtype(scale=True) does
+    else return ld1<TT>((const char*)base + idx * TT::SZ);
 }
-template <class TT> __device__ __forceinline__ void st_img(void* base, long long idx, float v, int u8) {
-    if (u8) ((uint8_t*)base)[idx] = (uint8_t)fminf(fmaxf(v * 255.0f + 0.5f, 0.0f), 255.0f);
+template <class TT, bool U8> __device__ __forceinline__ void st_img(void* base, long long idx, float v) {
+    if constexpr (U8) ((uint8_t*)base)[idx] = (uint8_t)fminf(fmaxf(v * 255.0f + 0.5f, 0.0f), 255.0f);
     else st1<TT>((char*)base + idx * TT::SZ, v);
 }
 
@@ -329,6 +329,73 @@ __device__ __forceinline__ bool map_tile(const ConvArgs& a, int& mtile, int& nti
     return mtile < a.mtiles && ntile < a.ntiles;
 }
 
+// PixelShuffle(2) + bicubic skip + residual add (+ clamp) -> NCHW image (reference model.py:926-930, 156, 162, 177).
+// U8: both images are uint8 (a compile-time switch: a per-load branch would serialise the 48 taps of every lane).
+template <class TT, int NT, bool U8>
+__device__ __forceinline__ void final_epilogue(const ConvArgs& a, f32x16 (&acc)[2][NT], char* ep, int lane, int b,
+                                               const int (&ey)[2], const int (&ex)[2]) {
+    constexpr int SZ = TT::SZ;
+    const int h = lane >> 5, r = lane & 31;
+    constexpr int ROWF = 80;  // 16 floats + 16 bytes pad
+    const long long plane_i = (long long)a.Hi * a.Wi;
+    const long long plane_o = (long long)a.Hout * a.Wout;
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+        const int y = ey[mf];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[mf][0][4 * q + j];
+            *(float4*)(ep + r * ROWF + (8 * q + 4 * h) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int px = lane >> 1, jj = lane & 1;
+        const int x = ex[mf] + px;
+        const int X = 2 * x + jj;
+        if (y < a.H && x < a.W) {
+            // horizontal taps of this output column
+            const int R = a.R;
+            const int kx = X / R, phx = X - kx * R;
+            const float sx = (phx + 0.5f) / (float)R - 0.5f;
+            const int fx = sx < 0.0f ? -1 : 0;
+            float cx[4];
+            cubic_coeffs(sx - (float)fx, cx);
+            int colx[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) colx[i] = min(max(kx + fx - 1 + i, 0), a.Wi - 1);
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2) {
+                const int Y = 2 * y + i2;
+                const int ky = Y / R, phy = Y - ky * R;
+                const float sy = (phy + 0.5f) / (float)R - 0.5f;
+                const int fy = sy < 0.0f ? -1 : 0;
+                float cy[4];
+                cubic_coeffs(sy - (float)fy, cy);
+                int rowy[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rowy[i] = min(max(ky + fy - 1 + i, 0), a.Hi - 1);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const long long ip = ((long long)b * 3 + c) * plane_i;
+                    float sres = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const long long rp = ip + (long long)rowy[i] * a.Wi;
+                        const float rowv = ld_img<TT, U8>(a.img, rp + colx[0]) * cx[0] + ld_img<TT, U8>(a.img, rp + colx[1]) * cx[1] +
+                                           ld_img<TT, U8>(a.img, rp + colx[2]) * cx[2] + ld_img<TT, U8>(a.img, rp + colx[3]) * cx[3];
+                        sres += rowv * cy[i];
+                    }
+                    float v = sres + *(const float*)(ep + px * ROWF + ((2 * i2 + jj) * 4 + c) * 4);
+                    if (a.clamp) v = fminf(fmaxf(v, 0.0f), 1.0f);
+                    st_img<TT, U8>(a.out, (((long long)b * 3 + c) * plane_o) + (long long)Y * a.Wout + X, v);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ================================================================================================
 // epilogue, shared by every convolution kernel.  Wave-local: each wave transposes its own 64-pixel x BN tile
 // through its own LDS region `ep`, so no workgroup barrier is needed (LDS operations of one wave execute in
@@ -344,64 +411,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const int epi, 
     const int h = lane >> 5, r = lane & 31;
     if (epi == EPI_FINAL) {
         if (IS_CONV) {
-            constexpr int ROWF = 80;  // 16 floats + 16 bytes pad
-            const long long plane_i = (long long)a.Hi * a.Wi;
-            const long long plane_o = (long long)a.Hout * a.Wout;
-#pragma unroll
-            for (int mf = 0; mf < 2; ++mf) {
-                const int y = ey[mf];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    float v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = acc[mf][0][4 * q + j];
-                    *(float4*)(ep + r * ROWF + (8 * q + 4 * h) * 4) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-                __builtin_amdgcn_wave_barrier();
-                const int px = lane >> 1, jj = lane & 1;
-                const int x = ex[mf] + px;
-                const int X = 2 * x + jj;
-                if (y < a.H && x < a.W) {
-                    // horizontal taps of this output column
-                    const int R = a.R;
-                    const int kx = X / R, phx = X - kx * R;
-                    const float sx = (phx + 0.5f) / (float)R - 0.5f;
-                    const int fx = sx < 0.0f ? -1 : 0;
-                    float cx[4];
-                    cubic_coeffs(sx - (float)fx, cx);
-                    int colx[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) colx[i] = min(max(kx + fx - 1 + i, 0), a.Wi - 1);
-#pragma unroll
-                    for (int i2 = 0; i2 < 2; ++i2) {
-                        const int Y = 2 * y + i2;
-                        const int ky = Y / R, phy = Y - ky * R;
-                        const float sy = (phy + 0.5f) / (float)R - 0.5f;
-                        const int fy = sy < 0.0f ? -1 : 0;
-                        float cy[4];
-                        cubic_coeffs(sy - (float)fy, cy);
-                        int rowy[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) rowy[i] = min(max(ky + fy - 1 + i, 0), a.Hi - 1);
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            const long long ip = ((long long)b * 3 + c) * plane_i;
-                            float sres = 0.0f;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const long long rp = ip + (long long)rowy[i] * a.Wi;
-                                const float rowv = ld_img<TT>(a.img, rp + colx[0], a.io_u8) * cx[0] + ld_img<TT>(a.img, rp + colx[1], a.io_u8) * cx[1] +
-                                                   ld_img<TT>(a.img, rp + colx[2], a.io_u8) * cx[2] + ld_img<TT>(a.img, rp + colx[3], a.io_u8) * cx[3];
-                                sres += rowv * cy[i];
-                            }
-                            float v = sres + *(const float*)(ep + px * ROWF + ((2 * i2 + jj) * 4 + c) * 4);
-                            if (a.clamp) v = fminf(fmaxf(v, 0.0f), 1.0f);
-                            st_img<TT>(a.out, (((long long)b * 3 + c) * plane_o) + (long long)Y * a.Wout + X, v, a.io_u8);
-                        }
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
+            if (a.io_u8) final_epilogue<TT, NT, true>(a, acc, ep, lane, b, ey, ex);
+            else final_epilogue<TT, NT, false>(a, acc, ep, lane, b, ey, ex);
         }
         return;
     }
@@ -1329,8 +1340,8 @@ hipError_t launch_pack_stem(const float* w, const float* b, float* dst, int c, i
 }
 
 // FanOutProjection (reference model.py:239-242): per-pixel 3 -> C affine, NCHW image -> plane-major features.
-template <class TT> __global__ void stem_kernel(const void* x, const float4* w4, void* out, long long total, long long HW,
-                                                int groups, int u8) {
+template <class TT, bool U8> __global__ void stem_kernel(const void* x, const float4* w4, void* out, long long total,
+                                                          long long HW, int groups) {
     constexpr int SZ = TT::SZ;
     constexpr int NPL = SZ / 2;  // planes per group of 8 channels
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1340,7 +1351,7 @@ template <class TT> __global__ void stem_kernel(const void* x, const float4* w4,
     const int g = (int)(t % groups);
     const long long b = t / groups;
     const long long xi = b * 3 * HW + p;
-    const float r0 = ld_img<TT>(x, xi, u8), r1 = ld_img<TT>(x, xi + HW, u8), r2 = ld_img<TT>(x, xi + 2 * HW, u8);
+    const float r0 = ld_img<TT, U8>(x, xi), r1 = ld_img<TT, U8>(x, xi + HW), r2 = ld_img<TT, U8>(x, xi + 2 * HW);
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -1363,9 +1374,9 @@ hipError_t launch_stem(int dtype, const void* x, const float* w4, void* out, int
     const long long total = HW * B * groups;
     const int blocks = (int)((total + 255) / 256);
     switch (dtype) {
-        case DT_F32: hipLaunchKernelGGL(stem_kernel<TF32>, dim3(blocks), dim3(256), 0, s, x, (const float4*)w4, out, total, HW, groups, u8); break;
-        case DT_BF16: hipLaunchKernelGGL(stem_kernel<TBF16>, dim3(blocks), dim3(256), 0, s, x, (const float4*)w4, out, total, HW, groups, u8); break;
-        case DT_F16: hipLaunchKernelGGL(stem_kernel<TF16>, dim3(blocks), dim3(256), 0, s, x, (const float4*)w4, out, total, HW, groups, u8); break;
+        case DT_F32: if (u8) hipLaunchKernelGGL((stem_kernel<TF32, true>), dim3(blocks), dim3(256), 0, s, x, (const float4*)w4, out, total, HW, groups); else hipLaunchKernelGGL((stem_kernel<TF32, false>), dim3(blocks), dim3(256), 0, s, x, (const float4*)w4, out, total, HW, groups); break;
+        case DT_BF16: if (u8) hipLaunchKernelGGL((stem_kernel<TBF16, true>), dim3(blocks), dim3(256), 0, s, x, (const float4*)w4, out, total, HW, groups); else hipLaunchKernelGGL((stem_kernel<TBF16, false>), dim3(blocks), dim3(256), 0, s, x, (const float4*)w4, out, total, HW, groups); break;
+        case DT_F16: if (u8) hipLaunchKernelGGL((stem_kernel<TF16, true>), dim3(blocks), dim3(256), 0, s, x, (const float4*)w4, out, total, HW, groups); else hipLaunchKernelGGL((stem_kernel<TF16, false>), dim3(blocks), dim3(256), 0, s, x, (const float4*)w4, out, total, HW, groups); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
