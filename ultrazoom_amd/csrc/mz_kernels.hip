@@ -35,14 +35,17 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct TF32 {
     static constexpr int SZ = 4;
     static constexpr int CK = 8;
+    static constexpr bool IS_BF16 = false;
 };
 struct TBF16 {
     static constexpr int SZ = 2;
     static constexpr int CK = 16;
+    static constexpr bool IS_BF16 = true;
 };
 struct TF16 {
     static constexpr int SZ = 2;
     static constexpr int CK = 16;
+    static constexpr bool IS_BF16 = false;
 };
 
 // ---- scalar conversions -----------------------------------------------------------------------
@@ -118,6 +121,39 @@ __device__ __forceinline__ float sigmoidf_(float v) {
 }
 
 // ---- one K-chunk of matrix work: acc[n][pixel] += W[n][k] * X[pixel][k] ------------------------
+// one 16-byte plane entry (8 channels of a 16-bit type, 4 of f32) <-> floats
+template <class TT> __device__ __forceinline__ void ld_unit(const void* p, float* v) {
+    if constexpr (TT::SZ == 4) {
+        ld4<TT>(p, v);
+    } else {
+        const uint4 t = *(const uint4*)p;
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (TT::IS_BF16) {
+                v[2 * i] = __builtin_bit_cast(float, w[i] << 16);
+                v[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u);
+            } else {
+                v[2 * i] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[i] & 0xffff));
+                v[2 * i + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[i] >> 16));
+            }
+        }
+    }
+}
+template <class TT> __device__ __forceinline__ void st_unit(void* p, const float* v) {
+    if constexpr (TT::SZ == 4) {
+        st4<TT>(p, v);
+    } else {
+        uint4 t;
+        if constexpr (TT::IS_BF16) {
+            t.x = pack_bf16(v[0], v[1]); t.y = pack_bf16(v[2], v[3]); t.z = pack_bf16(v[4], v[5]); t.w = pack_bf16(v[6], v[7]);
+        } else {
+            t.x = pack_f16(v[0], v[1]); t.y = pack_f16(v[2], v[3]); t.z = pack_f16(v[4], v[5]); t.w = pack_f16(v[6], v[7]);
+        }
+        *(uint4*)p = t;
+    }
+}
+
 template <class TT> __device__ __forceinline__ void mma(f32x16& acc, const u32x4& w, const u32x4& x);
 template <> __device__ __forceinline__ void mma<TBF16>(f32x16& acc, const u32x4& w, const u32x4& x) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x),
@@ -417,82 +453,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const int epi, 
         return;
     }
 
-    if (!IS_CONV) {
-        // 1x1 kernels (residual mix, PixelCrush).
-        // Direct stores.  An accumulator quad = 4 consecutive channels of the lane's pixel = half (16-bit types) or all (f32)
-        // of one 16-byte plane entry; lanes (h, r) and (1-h, r) hold the two halves, and r walks 32 consecutive pixels, so
-        // one store instruction covers 512 contiguous bytes of a plane: no LDS transpose is needed in the plane-major layout.
-        constexpr int PPU = SZ == 2 ? 8 : 4;  // channels per plane
-        const long long hwo = (long long)a.Ho * a.Wo;
-        const long long M = (long long)a.B * hwo;
-    #pragma unroll
-        for (int mf = 0; mf < 2; ++mf) {
-            int bimg = -1;       // image index, -1 = pixel outside the tensor
-            long long pix = 0;   // y * Wo + x inside the image
-            int py = 0, pxx = 0;
-            if (IS_CONV) {
-                py = ey[mf];
-                pxx = ex[mf] + r;
-                if (py < a.H && pxx < a.W) {
-                    bimg = b;
-                    pix = (long long)py * a.W + pxx;
-                }
-            } else {
-                const long long m = em[mf] + r;
-                if (m < M) {
-                    bimg = (int)(m / hwo);
-                    pix = m - (long long)bimg * hwo;
-                }
-            }
-            if (bimg < 0) continue;
-            const long long plane_o = (IS_CONV && epi == EPI_D2S) ? (long long)a.Hout * a.Wout * 16 : hwo * 16;
-            char* const obase = (char*)a.out + (long long)bimg * a.p_out * plane_o;
-    #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-    #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float v[4];
-    #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = acc[mf][nt][4 * q + j];
-                    const int n = nbase + 32 * nt + 8 * q + 4 * h;
-                    if (silu) {
-    #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = v[j] * sigmoidf_(v[j]);
-                    }
-                    if (IS_CONV && epi == EPI_D2S) {
-                        if (n < 4 * a.cp_out) {
-                            const int ij = n / a.cp_out;
-                            const int c = n - ij * a.cp_out;
-                            const int Y = 2 * py + (ij >> 1), X = 2 * pxx + (ij & 1);
-                            const int plane = c / PPU, inner = (c - plane * PPU) * SZ;
-                            st4<TT>(obase + plane * plane_o + ((long long)Y * a.Wout + X) * 16 + inner, v);
-                        }
-                    } else if (n < a.cp_out) {
-                        const int plane = n / PPU, inner = (n - plane * PPU) * SZ;
-                        if (epi == EPI_MIX) {
-                            float xv[4], zv[4];
-                            ld4<TT>((const char*)a.in0 + (((long long)bimg * a.p0 + plane) * hwo + pix) * 16 + inner, xv);
-                            ld4<TT>((const char*)a.in1 + (((long long)bimg * a.p1 + plane) * hwo + pix) * 16 + inner, zv);
-    #pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] = xv[j] + a.mix_scale * sigmoidf_(v[j]) * (zv[j] - xv[j]);
-                        }
-                        st4<TT>(obase + plane * plane_o + pix * 16 + inner, v);
-                    }
-                }
-            }
-        }
-        return;
-    }
-
-    constexpr int ROWB = BN * SZ + 16;
-    constexpr int UPP = BN * SZ / 16;  // 16-byte units per pixel row
-    constexpr int UPW = UPP / 2;       // units per lane (32 pixels * UPP / 64 lanes)
+    // Direct 16-byte stores, no LDS.  An accumulator quad = 4 consecutive channels of the lane's pixel.  f32: that is one
+    // 16-byte plane entry.  16-bit types: lanes (0, r) and (1, r) hold the two halves of an entry, so two quads are
+    // exchanged with v_permlane32_swap: afterwards lane (0, r) owns all 8 channels of the even quad's plane and lane
+    // (1, r) those of the odd quad's plane.  r walks 32 consecutive pixels: one store instruction writes two
+    // 512-byte runs.
     constexpr int PPU = SZ == 2 ? 8 : 4;  // channels per plane (= per 16-byte unit)
+    constexpr int UNITS = SZ == 2 ? 2 : 4;  // store units this lane produces per 32-channel accumulator tile
     const long long hwo = (long long)a.Ho * a.Wo;
     const long long M = (long long)a.B * hwo;
+    const bool d2s = IS_CONV && epi == EPI_D2S;
 #pragma unroll
     for (int mf = 0; mf < 2; ++mf) {
-        // Pixel of this lane: the accumulator column (lane & 31) and the pixel this lane stores below coincide.
         int bimg = -1;       // image index, -1 = pixel outside the tensor
         long long pix = 0;   // y * Wo + x inside the image
         int py = 0, pxx = 0;
@@ -510,53 +482,58 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const int epi, 
                 pix = m - (long long)bimg * hwo;
             }
         }
+        const long long plane_o = d2s ? (long long)a.Hout * a.Wout * 16 : hwo * 16;
+        char* const obase = (char*)a.out + (long long)(bimg < 0 ? 0 : bimg) * a.p_out * plane_o;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float v[4];
+            for (int u = 0; u < UNITS; ++u) {
+                float v[PPU];
+                int cu;  // 16-byte unit index inside this workgroup's BN channels
+                if constexpr (SZ == 2) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[mf][nt][4 * q + j];
-                const int nloc = 32 * nt + 8 * q + 4 * h;
+                    for (int j = 0; j < 4; ++j) {
+                        const float ea = acc[mf][nt][8 * u + j], eb = acc[mf][nt][8 * u + 4 + j];
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, ea),
+                                                                         __builtin_bit_cast(uint32_t, eb), false, false);
+                        const uint32_t s0 = sw[0], s1 = sw[1];
+                        v[j] = __builtin_bit_cast(float, s0);
+                        v[4 + j] = __builtin_bit_cast(float, s1);
+                    }
+                    cu = 4 * nt + 2 * u + h;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[mf][nt][4 * u + j];
+                    cu = 8 * nt + 2 * u + h;
+                }
+                const int n = nbase + cu * PPU;
                 if (silu) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = v[j] * sigmoidf_(v[j]);
+                    for (int j = 0; j < PPU; ++j) v[j] = v[j] * sigmoidf_(v[j]);
                 }
-                if (epi == EPI_MIX) {
-                    float xv[4] = {0.f, 0.f, 0.f, 0.f}, zv[4] = {0.f, 0.f, 0.f, 0.f};
-                    const int n = nbase + nloc;
-                    if (bimg >= 0 && n < a.cp_out) {
-                        const int plane = n / PPU, inner = (n - plane * PPU) * SZ;
-                        ld4<TT>((const char*)a.in0 + (((long long)bimg * a.p0 + plane) * hwo + pix) * 16 + inner, xv);
-                        ld4<TT>((const char*)a.in1 + (((long long)bimg * a.p1 + plane) * hwo + pix) * 16 + inner, zv);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = xv[j] + a.mix_scale * sigmoidf_(v[j]) * (zv[j] - xv[j]);
-                }
-                st4<TT>(ep + r * ROWB + nloc * SZ, v);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        // read back: lane -> pixel (lane & 31) of planes (lane >> 5) + 2 i: 32 consecutive pixels of one plane are
-        // 512 contiguous bytes in HBM
-#pragma unroll
-        for (int i = 0; i < UPW; ++i) {
-            const int cu = h + 2 * i;
-            const uint4 val = *(const uint4*)(ep + r * ROWB + cu * 16);
-            const int n = nbase + cu * PPU;
-            if (bimg < 0) continue;
-            if (IS_CONV && epi == EPI_D2S) {
-                if (n < 4 * a.cp_out) {
+                if (bimg < 0) continue;
+                char* dst;
+                if (d2s) {
+                    if (n >= 4 * a.cp_out) continue;
                     const int ij = n / a.cp_out;
                     const int c = n - ij * a.cp_out;
                     const int Y = 2 * py + (ij >> 1), X = 2 * pxx + (ij & 1);
-                    *(uint4*)((char*)a.out + ((((long long)b * a.p_out + c / PPU) * a.Hout + Y) * a.Wout + X) * 16) = val;
+                    dst = obase + (c / PPU) * plane_o + ((long long)Y * a.Wout + X) * 16;
+                } else {
+                    if (n >= a.cp_out) continue;
+                    const int plane = n / PPU;
+                    if (epi == EPI_MIX) {
+                        float xv[PPU], zv[PPU];
+                        ld_unit<TT>((const char*)a.in0 + (((long long)bimg * a.p0 + plane) * hwo + pix) * 16, xv);
+                        ld_unit<TT>((const char*)a.in1 + (((long long)bimg * a.p1 + plane) * hwo + pix) * 16, zv);
+#pragma unroll
+                        for (int j = 0; j < PPU; ++j) v[j] = xv[j] + a.mix_scale * sigmoidf_(v[j]) * (zv[j] - xv[j]);
+                    }
+                    dst = obase + plane * plane_o + pix * 16;
                 }
-            } else if (n < a.cp_out) {
-                *(uint4*)((char*)a.out + (((long long)bimg * a.p_out + n / PPU) * hwo + pix) * 16) = val;
+                st_unit<TT>(dst, v);
             }
         }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
