@@ -60,6 +60,58 @@ def test_conv3x3(dt, case):
         assert pad_part(out, cout).abs().max().item() == 0.0, "pad channels must be written as zeros"
 
 
+PERSIST_CASES = [
+    # B, H, W, cin, cout, silu : enough tiles that 8 or 16 persistent workgroups each walk several of them
+    (2, 45, 100, 32, 96, 1),    # 16x32 tiles, ragged edges, one N tile
+    (1, 40, 200, 48, 192, 0),   # 8x64 tiles, two N tiles (weights change at tile boundaries)
+    (3, 33, 65, 16, 288, 1),    # one K-stage per tile: every barrier is a tile boundary
+    (1, 70, 70, 96, 40, 0),     # padded N, 6 K-stages
+]
+
+
+@pytest.mark.parametrize("wgs", [8, 16])
+@pytest.mark.parametrize("dt", list(DTYPES))
+@pytest.mark.parametrize("case", PERSIST_CASES)
+def test_conv3x3_persistent(dt, case, wgs, monkeypatch):
+    """The persistent kernel (one workgroup per CU walking many tiles, LDS ring turning across tile boundaries) must
+    give the same bits as the one-tile-per-workgroup kernel, and both must match the oracle."""
+    dtype = DTYPES[dt]
+    B, H, W, cin, cout, silu = case
+    x = q(rnd((B, cin, H, W), 11), dtype)
+    w = q(wrnd((cout, cin, 3, 3), 12), dtype)
+    outs = []
+    for env in ({"MZ_PERSIST_WGS": str(wgs)}, {"MZ_NO_PERSIST": "1"}):
+        monkeypatch.delenv("MZ_PERSIST_WGS", raising=False)
+        monkeypatch.delenv("MZ_NO_PERSIST", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = alloc_act(B, cout, H, W, dtype)
+        op_conv(dtype, 0, to_act(x, dtype), None, w, 0.0, out, B, H, W, cin, cout, silu=silu)
+        outs.append(out)
+    want = F.conv2d(x, w, padding=1)
+    if silu:
+        want = F.silu(want)
+    got = from_act(outs[0], cout)
+    err = (got - want).abs().max().item()
+    assert err < OP_TOL[dt], f"max-abs {err}"
+    assert torch.equal(outs[0], outs[1]), "persistent and per-tile kernels must agree bit for bit"
+
+
+@pytest.mark.parametrize("dt", list(DTYPES))
+def test_subpixel_conv_persistent(dt, monkeypatch):
+    dtype = DTYPES[dt]
+    B, H, W, cin, cout, Hout, Wout = 2, 40, 70, 32, 192, 81, 140
+    cq = cout // 4
+    x = q(rnd((B, cin, H, W), 13), dtype)
+    w = q(wrnd((cout, cin, 3, 3), 14), dtype)
+    monkeypatch.setenv("MZ_PERSIST_WGS", "8")
+    out = alloc_act(B, cq, Hout, Wout, dtype)
+    op_conv(dtype, 1, to_act(x, dtype), None, w, 0.0, out, B, H, W, cin, cout, Hout, Wout)
+    want = oracle.fit_to(oracle.subpixel_conv(x, w), (Hout, Wout))
+    err = (from_act(out, cq) - want).abs().max().item()
+    assert err < OP_TOL[dt], f"max-abs {err}"
+
+
 D2S_CASES = [
     # B, H, W, cin, cout(=4*cq), Hout, Wout
     (1, 7, 9, 32, 64, 14, 18),

@@ -496,6 +496,26 @@ extern "C" int mz_debug_read(unsigned long long* host_dst) {
     return hipMemcpy(host_dst, b, 16 * 64 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -6;
 }
 
+// workgroups of a persistent launch: one per CU, a multiple of 8 (one equal share per XCD).
+// MZ_NO_PERSIST=1: one workgroup per tile everywhere (A/B timing); MZ_PERSIST_WGS=n: force n (tests use 8 / 16 so that
+// small images walk several tiles per workgroup).
+static int persistent_workgroups() {
+    if (getenv("MZ_NO_PERSIST") != nullptr) return 0;
+    if (const char* e = getenv("MZ_PERSIST_WGS")) {
+        const int n = atoi(e) / 8 * 8;
+        return n > 0 ? n : 0;
+    }
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0, n = 0;
+        cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+            cus = n / 8 * 8;
+    }
+    return cus;
+}
+
 struct Runner {
     mz_handle* h;
     hipStream_t s;
@@ -504,6 +524,7 @@ struct Runner {
     bool wide_tiles = getenv("MZ_NO_WIDE") == nullptr;  // MZ_NO_WIDE=1 forces the 256-pixel kernel (A/B timing)
     bool no_fuse = getenv("MZ_NO_FUSE") != nullptr;     // MZ_NO_FUSE=1 keeps conv2 and the mix as two launches
     int io_u8 = 0;                                        // images at both ends are uint8 (mz_forward_u8)
+    int persist_wgs = persistent_workgroups();            // 0 = MZ_NO_PERSIST: one workgroup per tile everywhere
 
     void prof_begin(ProfRec*& r, double flops, double bytes, int is_conv3) {
         r = nullptr;
@@ -612,6 +633,7 @@ struct Runner {
         const double sz = dtype_size(dtype);
         const double px = (double)B * H * W;
         pick_order(a, c, px * c.cp0 * sz);
+        if (mode != MODE_CONV3 && (epi == EPI_STORE || epi == EPI_D2S) && a.grid > persist_wgs) a.persist = persist_wgs;
         ProfRec* r;
         prof_begin(r, 2.0 * px * 9.0 * c.cin * c.cout + extra_flops, px * (c.cin + c.cout) * sz + 9.0 * c.cin * c.cout * sz, 1);
         if (r) { r->kind = 0; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.gm * 1000 + a.gn; }

@@ -64,6 +64,7 @@ struct ConvArgs {
     int Hi, Wi;        // FINAL: img size
     int clamp;
     int io_u8;         // EPI_FINAL: img and out are uint8 images (scaled by 1/255 on read, x255 + 0.5 on write)
+    int persist;       // > 0: launch the persistent wide 3x3 kernel with this many workgroups (a multiple of 8)
     int use_glds;      // stage through global_load_lds (1) or through registers (0)
     unsigned long long* dbg;  // -DMZ_STAMP diagnostic builds: per-stage s_memtime stamps of one workgroup
 };

@@ -68,6 +68,18 @@ template <class TT, bool U8> __device__ __forceinline__ float ld_img(const void*
     if constexpr (U8) return (float)((const uint8_t*)base)[idx] / 255.0f;  // a true division, as ToDtype(scale=True) does
     else return ld1<TT>((const char*)base + idx * TT::SZ);
 }
+// raw element load / conversion split, so that a batch of loads can be issued before the first conversion
+template <class TT, bool U8> __device__ __forceinline__ uint32_t ld_img_raw(const void* base, long long idx) {
+    if constexpr (U8) return ((const uint8_t*)base)[idx];
+    else if constexpr (TT::SZ == 4) return ((const uint32_t*)base)[idx];
+    else return ((const uint16_t*)base)[idx];
+}
+template <class TT, bool U8> __device__ __forceinline__ float img_cvt(uint32_t raw) {
+    if constexpr (U8) return (float)raw / 255.0f;
+    else if constexpr (TT::SZ == 4) return __builtin_bit_cast(float, raw);
+    else if constexpr (TT::IS_BF16) return __builtin_bit_cast(float, raw << 16);
+    else return (float)__builtin_bit_cast(_Float16, (uint16_t)raw);
+}
 template <class TT, bool U8> __device__ __forceinline__ void st_img(void* base, long long idx, float v) {
     if constexpr (U8) ((uint8_t*)base)[idx] = (uint8_t)fminf(fmaxf(v * 255.0f + 0.5f, 0.0f), 255.0f);
     else st1<TT>((char*)base + idx * TT::SZ, v);
@@ -79,6 +91,10 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
     return (uint32_t)lo | ((uint32_t)hi << 16);
 }
 __device__ __forceinline__ uint32_t pack_f16(float a, float b) {
+    // Opaque: the value is rounded to f32 first in EVERY kernel.  Left alone, hipcc folds a preceding multiply into a
+    // v_fma_mix* form (one rounding, straight to f16) in some instantiations and not in others, and two kernels
+    // that must agree bit for bit (per-tile vs persistent, any batch size) then differ in the last f16 bit.
+    asm("" : "+v"(a), "+v"(b));
     uint16_t lo = __builtin_bit_cast(uint16_t, (_Float16)a);
     uint16_t hi = __builtin_bit_cast(uint16_t, (_Float16)b);
     return (uint32_t)lo | ((uint32_t)hi << 16);
@@ -351,6 +367,17 @@ __device__ __forceinline__ int fdiv(int x, int d, float inv) {
     return q;
 }
 
+// logical id -> tile (the group walk)
+__device__ __forceinline__ bool tile_of(const ConvArgs& a, int L, int& mtile, int& ntile) {
+    const int gsz = a.gm * a.gn;
+    const int group = fdiv(L, gsz, a.inv_gsz), within = L - group * gsz;
+    const int gi_n = fdiv(group, a.groups_m, a.inv_groups_m), gi_m = group - gi_n * a.groups_m;
+    const int mi = fdiv(within, a.gn, a.inv_gn), ni = within - mi * a.gn;
+    mtile = gi_m * a.gm + mi;
+    ntile = gi_n * a.gn + ni;
+    return mtile < a.mtiles && ntile < a.ntiles;
+}
+
 __device__ __forceinline__ bool map_tile(const ConvArgs& a, int& mtile, int& ntile) {
     const int nblk = gridDim.x;
     const int bid = blockIdx.x;
@@ -389,6 +416,13 @@ __device__ __forceinline__ void final_epilogue(const ConvArgs& a, f32x16 (&acc)[
         const int px = lane >> 1, jj = lane & 1;
         const int x = ex[mf] + px;
         const int X = 2 * x + jj;
+        // the conv results of this lane's six outputs, read BEFORE any image load is issued: hipcc drains vmcnt to 0 in
+        // front of every LDS read of a kernel that uses LDS-DMA, which would serialise the 96 image loads below
+        float zres[2][3];
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) zres[i2][c] = *(const float*)(ep + px * ROWF + ((2 * i2 + jj) * 4 + c) * 4);
         if (y < a.H && x < a.W) {
             // horizontal taps of this output column
             const int R = a.R;
@@ -411,18 +445,35 @@ __device__ __forceinline__ void final_epilogue(const ConvArgs& a, f32x16 (&acc)[
                 int rowy[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) rowy[i] = min(max(ky + fy - 1 + i, 0), a.Hi - 1);
+                // all 48 taps of this output row first (one opaque statement per channel pins "every load issued before
+                // any use": left alone, hipcc serialises them as load -> wait -> multiply), then the arithmetic
+                uint32_t raw[3][16];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const long long ip = ((long long)b * 3 + c) * plane_i;
-                    float sres = 0.0f;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const long long rp = ip + (long long)rowy[i] * a.Wi;
-                        const float rowv = ld_img<TT, U8>(a.img, rp + colx[0]) * cx[0] + ld_img<TT, U8>(a.img, rp + colx[1]) * cx[1] +
-                                           ld_img<TT, U8>(a.img, rp + colx[2]) * cx[2] + ld_img<TT, U8>(a.img, rp + colx[3]) * cx[3];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) raw[c][4 * i + k] = ld_img_raw<TT, U8>(a.img, rp + colx[k]);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    asm volatile("" : "+v"(raw[c][0]), "+v"(raw[c][1]), "+v"(raw[c][2]), "+v"(raw[c][3]), "+v"(raw[c][4]),
+                                      "+v"(raw[c][5]), "+v"(raw[c][6]), "+v"(raw[c][7]), "+v"(raw[c][8]), "+v"(raw[c][9]),
+                                      "+v"(raw[c][10]), "+v"(raw[c][11]), "+v"(raw[c][12]), "+v"(raw[c][13]),
+                                      "+v"(raw[c][14]), "+v"(raw[c][15]));
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float sres = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float rowv = img_cvt<TT, U8>(raw[c][4 * i]) * cx[0] + img_cvt<TT, U8>(raw[c][4 * i + 1]) * cx[1] +
+                                           img_cvt<TT, U8>(raw[c][4 * i + 2]) * cx[2] + img_cvt<TT, U8>(raw[c][4 * i + 3]) * cx[3];
                         sres += rowv * cy[i];
                     }
-                    float v = sres + *(const float*)(ep + px * ROWF + ((2 * i2 + jj) * 4 + c) * 4);
+                    float v = sres + zres[i2][c];
                     if (a.clamp) v = fminf(fmaxf(v, 0.0f), 1.0f);
                     st_img<TT, U8>(a.out, (((long long)b * 3 + c) * plane_o) + (long long)Y * a.Wout + X, v);
                 }
@@ -432,27 +483,12 @@ __device__ __forceinline__ void final_epilogue(const ConvArgs& a, f32x16 (&acc)[
     }
 }
 
-// ================================================================================================
-// epilogue, shared by every convolution kernel.  Wave-local: each wave transposes its own 64-pixel x BN tile
-// through its own LDS region `ep`, so no workgroup barrier is needed (LDS operations of one wave execute in
-// program order).  Pixel geometry of the wave's two M fragments:
-//   IS_CONV: fragment mf covers pixels (ey[mf], ex[mf] + r) of image b;   else: linear pixels em[mf] + r.
-// ================================================================================================
-template <class TT, int NT, bool IS_CONV>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const int epi, const int silu, f32x16 (&acc)[2][NT], char* ep,
-                                              int lane, int nbase, int b, const int (&ey)[2], const int (&ex)[2],
-                                              const long long (&em)[2]) {
+// Store epilogues (STORE, D2S, MIX), specialised at compile time; `conv_epilogue` below dispatches.
+template <class TT, int NT, bool IS_CONV, int EPI, bool SILU>
+__device__ __forceinline__ void store_epilogue(const ConvArgs& a, f32x16 (&acc)[2][NT], int lane, int nbase, int b,
+                                               const int (&ey)[2], const int (&ex)[2], const long long (&em)[2]) {
     constexpr int SZ = TT::SZ;
-    constexpr int BN = 32 * NT;
     const int h = lane >> 5, r = lane & 31;
-    if (epi == EPI_FINAL) {
-        if (IS_CONV) {
-            if (a.io_u8) final_epilogue<TT, NT, true>(a, acc, ep, lane, b, ey, ex);
-            else final_epilogue<TT, NT, false>(a, acc, ep, lane, b, ey, ex);
-        }
-        return;
-    }
-
     // Direct 16-byte stores, no LDS.  An accumulator quad = 4 consecutive channels of the lane's pixel.  f32: that is one
     // 16-byte plane entry.  16-bit types: lanes (0, r) and (1, r) hold the two halves of an entry, so two quads are
     // exchanged with v_permlane32_swap: afterwards lane (0, r) owns all 8 channels of the even quad's plane and lane
@@ -462,7 +498,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const int epi, 
     constexpr int UNITS = SZ == 2 ? 2 : 4;  // store units this lane produces per 32-channel accumulator tile
     const long long hwo = (long long)a.Ho * a.Wo;
     const long long M = (long long)a.B * hwo;
-    const bool d2s = IS_CONV && epi == EPI_D2S;
+    constexpr bool d2s = IS_CONV && EPI == EPI_D2S;
 #pragma unroll
     for (int mf = 0; mf < 2; ++mf) {
         int bimg = -1;       // image index, -1 = pixel outside the tensor
@@ -507,13 +543,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const int epi, 
                     cu = 8 * nt + 2 * u + h;
                 }
                 const int n = nbase + cu * PPU;
-                if (silu) {
+                if constexpr (SILU) {
 #pragma unroll
                     for (int j = 0; j < PPU; ++j) v[j] = v[j] * sigmoidf_(v[j]);
                 }
                 if (bimg < 0) continue;
                 char* dst;
-                if (d2s) {
+                if constexpr (d2s) {
                     if (n >= 4 * a.cp_out) continue;
                     const int ij = n / a.cp_out;
                     const int c = n - ij * a.cp_out;
@@ -522,7 +558,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const int epi, 
                 } else {
                     if (n >= a.cp_out) continue;
                     const int plane = n / PPU;
-                    if (epi == EPI_MIX) {
+                    if constexpr (!IS_CONV && EPI == EPI_MIX) {  // only the 1x1 kernel runs the mix
                         float xv[PPU], zv[PPU];
                         ld_unit<TT>((const char*)a.in0 + (((long long)bimg * a.p0 + plane) * hwo + pix) * 16, xv);
                         ld_unit<TT>((const char*)a.in1 + (((long long)bimg * a.p1 + plane) * hwo + pix) * 16, zv);
@@ -534,6 +570,33 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const int epi, 
                 st_unit<TT>(dst, v);
             }
         }
+    }
+}
+
+// ================================================================================================
+// epilogue, shared by every convolution kernel.  Wave-local (no workgroup barrier); only FINAL touches LDS (the
+// wave's own region `ep`).  Pixel geometry of the wave's two M fragments:
+//   IS_CONV: fragment mf covers pixels (ey[mf], ex[mf] + r) of image b;   else: linear pixels em[mf] + r.
+// ================================================================================================
+template <class TT, int NT, bool IS_CONV>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const int epi, const int silu, f32x16 (&acc)[2][NT], char* ep,
+                                              int lane, int nbase, int b, const int (&ey)[2], const int (&ex)[2],
+                                              const long long (&em)[2]) {
+    if (epi == EPI_FINAL) {
+        if (IS_CONV) {
+            if (a.io_u8) final_epilogue<TT, NT, true>(a, acc, ep, lane, b, ey, ex);
+            else final_epilogue<TT, NT, false>(a, acc, ep, lane, b, ey, ex);
+        }
+        return;
+    }
+    if constexpr (IS_CONV) {
+        if (epi == EPI_D2S) store_epilogue<TT, NT, true, EPI_D2S, false>(a, acc, lane, nbase, b, ey, ex, em);
+        else if (silu) store_epilogue<TT, NT, true, EPI_STORE, true>(a, acc, lane, nbase, b, ey, ex, em);
+        else store_epilogue<TT, NT, true, EPI_STORE, false>(a, acc, lane, nbase, b, ey, ex, em);
+    } else {
+        if (epi == EPI_MIX) store_epilogue<TT, NT, false, EPI_MIX, false>(a, acc, lane, nbase, b, ey, ex, em);
+        else if (silu) store_epilogue<TT, NT, false, EPI_STORE, true>(a, acc, lane, nbase, b, ey, ex, em);
+        else store_epilogue<TT, NT, false, EPI_STORE, false>(a, acc, lane, nbase, b, ey, ex, em);
     }
 }
 
@@ -927,6 +990,185 @@ __global__ __launch_bounds__(576, 3) void conv3w_kernel(const ConvArgs a) {
     }
 }
 
+// ================================================================================================
+// 3x3 convolution, wide tile, PERSISTENT: one workgroup per CU walks its XCD's share of the tile list, and the
+// LDS ring simply keeps turning across tile boundaries.  Two loader waves issue every LDS-DMA (wave 8 the halo
+// images, wave 9 the weight stages), two K-stages ahead of the compute waves -- also across a tile boundary, so
+// the first two stages of the next tile land while this tile's last stages and its epilogue run.  The compute
+// waves issue no loads at all: they never wait on vmcnt, so the epilogue's stores drain under the next tile's
+// MFMAs instead of at the end of a workgroup's life.  (Store epilogues only: STORE / D2S need no LDS.)
+// ================================================================================================
+template <class TT, int NT, int MODE>
+__global__ __launch_bounds__(640) void conv3p_kernel(const ConvArgs a) {
+    using G = Geo<MODE>;
+    constexpr int A_SLOT = G::A_ENT * 16;
+    constexpr int A_INSTR = G::A_ENT / 64;
+    constexpr int B_PIECES = 9 * NT;
+    constexpr int B_SLOT = B_PIECES * 1024;
+    constexpr int SLOT = A_SLOT + B_SLOT;
+    constexpr int BN = 32 * NT;
+    static_assert(2 * B_PIECES < 64 && 2 * A_INSTR < 64, "vmcnt is a 6-bit counter");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7 compute, 8 = halo loader, 9 = weight loader
+    const int nstages = a.nchunks;
+
+    // this workgroup's tile list: logical ids base + pos, base + pos + step, ... inside its XCD's contiguous range
+    const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3, step = gridDim.x >> 3;
+    const int q = a.grid >> 3, rem = a.grid & 7;
+    const int cnt = q + (xcd < rem ? 1 : 0);
+    const int base = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+    // first valid (non-padding) tile at or after list position i; cnt when the list is exhausted
+    auto seek = [&](int i, int& mtile, int& ntile) {
+        while (i < cnt && !tile_of(a, base + i, mtile, ntile)) i += step;
+        return i;
+    };
+    int mtile = 0, ntile = 0;
+    int cur = seek(pos, mtile, ntile);
+    if (cur >= cnt) return;  // uniform over the workgroup
+
+    const int tpi = a.tiles_x * a.tiles_y;
+    auto tile_origin = [&](int mt, int& b, int& y0, int& x0) {
+        b = fdiv(mt, tpi, a.inv_tpi);
+        const int trem = mt - b * tpi;
+        const int tyi = fdiv(trem, a.tiles_x, a.inv_tiles_x);
+        y0 = tyi * G::TH;
+        x0 = (trem - tyi * a.tiles_x) * G::TW;
+    };
+
+    if (w >= 8) {
+        // ------------------------- loader waves -------------------------
+        // how many stages this workgroup will run in total (the compute waves meet us at one barrier per stage)
+        int ntl = 0;
+        {
+            int mt_, nt_;
+            for (int i = cur; i < cnt; i = seek(i + step, mt_, nt_)) ++ntl;
+        }
+        const int total = ntl * nstages;
+        const long long plane_in = (long long)a.H * a.W * 16;
+        int l_pos = cur, l_st = 0, l_slot = 0, pending = 0;
+        bool l_ok = true;
+        if (w == 9) {
+            const char* wsrc = (const char*)a.wpk + (size_t)ntile * nstages * B_SLOT + lane * 16;
+            auto issue = [&]() {
+                if (!l_ok) return;
+                const char* src = wsrc + (size_t)l_st * B_SLOT;
+                char* dst = smem + l_slot * SLOT + A_SLOT;
+#pragma unroll
+                for (int j = 0; j < B_PIECES; ++j) glds16(src + j * 1024, dst + j * 1024);
+                ++pending;
+                l_slot = l_slot == 2 ? 0 : l_slot + 1;
+                if (++l_st == nstages) {
+                    l_st = 0;
+                    int mt_, nt_ = 0;
+                    l_pos = seek(l_pos + step, mt_, nt_);
+                    l_ok = l_pos < cnt;
+                    wsrc = (const char*)a.wpk + (size_t)nt_ * nstages * B_SLOT + lane * 16;
+                }
+            };
+            issue();
+            issue();
+            for (int g = 0; g < total; ++g) {
+                if (pending >= 2) wait_vmcnt<B_PIECES>(); else wait_vmcnt<0>();
+                --pending;
+                __builtin_amdgcn_s_barrier();
+                issue();
+            }
+        } else {
+            // halo image: instruction j covers entries [64 j, 64 j + 64); per-lane byte offsets inside image b
+            uint32_t aoff[A_INSTR];
+            const char* img = nullptr;
+            auto set_tile = [&](int mt) {
+                int b, y0, x0;
+                tile_origin(mt, b, y0, x0);
+                img = (const char*)a.in0 + (long long)b * a.p0 * plane_in;
+#pragma unroll
+                for (int j = 0; j < A_INSTR; ++j) {
+                    const int e = 64 * j + lane;
+                    const int plane = e >= G::PLANE_ENT ? 1 : 0;
+                    const int p = e - plane * G::PLANE_ENT;
+                    const int py = p / G::ROWW, px = p - py * G::ROWW;
+                    const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+                    const bool ok = (p < G::NPIX) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                    aoff[j] = ok ? (uint32_t)(((plane * a.H + gy) * a.W + gx) * 16) : 0xffffffffu;
+                }
+            };
+            set_tile(mtile);
+            auto issue = [&]() {
+                if (!l_ok) return;
+                const char* src = img + 2LL * l_st * plane_in;
+                char* dst = smem + l_slot * SLOT;
+#pragma unroll
+                for (int j = 0; j < A_INSTR; ++j)
+                    glds16(aoff[j] != 0xffffffffu ? src + aoff[j] : (const char*)a.zero, dst + j * 1024);
+                ++pending;
+                l_slot = l_slot == 2 ? 0 : l_slot + 1;
+                if (++l_st == nstages) {
+                    l_st = 0;
+                    int mt_ = 0, nt_;
+                    l_pos = seek(l_pos + step, mt_, nt_);
+                    l_ok = l_pos < cnt;
+                    if (l_ok) set_tile(mt_);
+                }
+            };
+            issue();
+            issue();
+            for (int g = 0; g < total; ++g) {
+                if (pending >= 2) wait_vmcnt<A_INSTR>(); else wait_vmcnt<0>();
+                --pending;
+                __builtin_amdgcn_s_barrier();
+                issue();
+            }
+        }
+        return;
+    }
+
+    // ------------------------- compute waves -------------------------
+    const int h = lane >> 5, r = lane & 31;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t a_lane = lds_base + h * G::PLANE + ((G::ROW_PER_WAVE * w) * G::ROWW + r) * 16;
+    const uint32_t b_lane = lds_base + A_SLOT + lane * 16;
+    const long long em[2] = {0, 0};
+    int slot = 0;
+    while (cur < cnt) {
+        int b, y0, x0;
+        tile_origin(mtile, b, y0, x0);
+        const int nbase = ntile * BN;
+        int ey[2], ex[2];
+        if (G::ROW_PER_WAVE == 2) {
+            ey[0] = y0 + 2 * w; ey[1] = y0 + 2 * w + 1;
+            ex[0] = x0; ex[1] = x0;
+        } else {
+            ey[0] = y0 + w; ey[1] = y0 + w;
+            ex[0] = x0; ex[1] = x0 + 32;
+        }
+        f32x16 acc[2][NT];
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mf][nt][i] = 0.0f;
+
+        for (int st = 0; st < nstages; ++st) {
+            __builtin_amdgcn_s_barrier();  // stage landed (the loaders waited for it); everyone is done with the slot two back
+            const uint32_t a_addr = a_lane + slot * SLOT;
+            const uint32_t b_addr = b_lane + slot * SLOT;
+            Frags<NT> fa, fb;
+            issue_reads<NT, MODE, 0>(fa, a_addr, b_addr);
+            wait_frags<NT>(fa);
+            run_items<TT, NT, MODE, 0, 9>(acc, fa, fb, a_addr, b_addr);
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+        if (a.epi == EPI_D2S) store_epilogue<TT, NT, true, EPI_D2S, false>(a, acc, lane, nbase, b, ey, ex, em);
+        else if (a.silu) store_epilogue<TT, NT, true, EPI_STORE, true>(a, acc, lane, nbase, b, ey, ex, em);
+        else store_epilogue<TT, NT, true, EPI_STORE, false>(a, acc, lane, nbase, b, ey, ex, em);
+        cur = seek(cur + step, mtile, ntile);
+    }
+}
+
 template <class TT, int NT, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
     using G = Geo<MODE>;
@@ -1141,6 +1383,8 @@ template <class TT, int NT, int MODE> static hipError_t launch_one(const ConvArg
         if constexpr (NT <= 3) {
             if (a.epi == EPI_FUSEDMIX)
                 hipLaunchKernelGGL((conv3w_kernel<TT, NT, MODE, true>), dim3(a.grid), dim3(576), lds, s, a);
+            else if (a.persist > 0 && (a.epi == EPI_STORE || a.epi == EPI_D2S))
+                hipLaunchKernelGGL((conv3p_kernel<TT, NT, MODE>), dim3(a.persist), dim3(640), lds, s, a);
             else
                 hipLaunchKernelGGL((conv3w_kernel<TT, NT, MODE, false>), dim3(a.grid), dim3(576), lds, s, a);
         } else {
@@ -1185,6 +1429,8 @@ template <class TT, int NT, int MODE> static hipError_t set_lds_one() {
     if constexpr (MODE == MODE_C3W16 || MODE == MODE_C3W8) {
         hipError_t e = hipFuncSetAttribute((const void*)conv3w_kernel<TT, NT, MODE, false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)conv3p_kernel<TT, NT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return e;
         return hipFuncSetAttribute((const void*)conv3w_kernel<TT, NT, MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    bytes);
