@@ -61,6 +61,10 @@ struct ConvW {
     int n_logical_padded = 0;
     void* packed = nullptr;
     size_t packed_sz = 0;
+    // second packing for the 16x16x32-MFMA kernel (16-bit types, wide 3x3 convs that are not the image head)
+    void* packed16 = nullptr;
+    size_t packed16_sz = 0;
+    int nchunks16 = 0;
     bool set = false;
 };
 
@@ -99,6 +103,10 @@ static void plan_conv(ConvW& c, int dtype, int mode, int cout, int cin, int kh, 
         c.nchunks = (c.nchunks + S - 1) / S * S;
     }
     c.packed_sz = packed_bytes(c.taps, c.nt, c.ntiles, c.nchunks);
+    if (mode == MODE_CONV3 && dtype != DT_F32 && in_map == SRC_PLAIN && out_map != OUT_FINAL && c.nt <= 3) {
+        c.nchunks16 = (c.cp0 + 31) / 32;
+        c.packed16_sz = packed_bytes(c.taps, 2 * c.nt, c.ntiles, c.nchunks16);
+    }
 }
 
 struct BlockW {
@@ -291,6 +299,8 @@ extern "C" int mz_create(const mz_config* cfg, int dtype, mz_handle** out) {
 static void free_conv(ConvW& c) {
     if (c.packed) (void)hipFree(c.packed);
     c.packed = nullptr;
+    if (c.packed16) (void)hipFree(c.packed16);
+    c.packed16 = nullptr;
 }
 
 extern "C" int mz_destroy(mz_handle* h) {
@@ -343,7 +353,13 @@ static int pack_conv(ConvW& c, int dtype, const float* w_dev, hipStream_t s) {
     p.taps = c.taps; p.nt = c.nt; p.ntiles = c.ntiles; p.nchunks = c.nchunks;
     p.out_map = c.out_map; p.cq = c.cq; p.cq_p = c.cq_p;
     p.in_map = c.in_map; p.c0 = c.c0; p.cp0 = c.cp0; p.c1 = c.c1;
+    p.frag16 = 0;
     HIPCHK(launch_pack(p, s));
+    if (c.packed16_sz) {
+        if (!c.packed16) HIPCHK(hipMalloc(&c.packed16, c.packed16_sz));
+        p.dst = c.packed16; p.frag16 = 1; p.nchunks = c.nchunks16;
+        HIPCHK(launch_pack(p, s));
+    }
     c.set = true;
     return MZ_OK;
 }
@@ -524,6 +540,7 @@ struct Runner {
     bool wide_tiles = getenv("MZ_NO_WIDE") == nullptr;  // MZ_NO_WIDE=1 forces the 256-pixel kernel (A/B timing)
     bool no_fuse = getenv("MZ_NO_FUSE") != nullptr;     // MZ_NO_FUSE=1 keeps conv2 and the mix as two launches
     int io_u8 = 0;                                        // images at both ends are uint8 (mz_forward_u8)
+    bool use_s16 = getenv("MZ_NO_S16") == nullptr;        // MZ_NO_S16=1 keeps 16-bit types on the 32x32x16 kernels (A/B timing)
     int persist_wgs = persistent_workgroups();            // 0 = MZ_NO_PERSIST: one workgroup per tile everywhere
 
     void prof_begin(ProfRec*& r, double flops, double bytes, int is_conv3) {
@@ -633,7 +650,16 @@ struct Runner {
         const double sz = dtype_size(dtype);
         const double px = (double)B * H * W;
         pick_order(a, c, px * c.cp0 * sz);
-        if (mode != MODE_CONV3 && (epi == EPI_STORE || epi == EPI_D2S) && a.grid > persist_wgs) a.persist = persist_wgs;
+        if (mode != MODE_CONV3 && (epi == EPI_STORE || epi == EPI_D2S) && persist_wgs > 0) {
+            // 16-bit types: the 16x16x32-MFMA kernel (persistent only; 32-bit halo offsets span four planes)
+            if (c.packed16 && use_s16 && (double)H * W * 64.0 < 4294967296.0) {
+                a.s16 = 1; a.wpk16 = c.packed16; a.nchunks16 = c.nchunks16;
+                const int need = (a.grid + 7) / 8 * 8;
+                a.persist = need < persist_wgs ? need : persist_wgs;
+            } else if (a.grid > persist_wgs) {
+                a.persist = persist_wgs;
+            }
+        }
         ProfRec* r;
         prof_begin(r, 2.0 * px * 9.0 * c.cin * c.cout + extra_flops, px * (c.cin + c.cout) * sz + 9.0 * c.cin * c.cout * sz, 1);
         if (r) { r->kind = 0; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.gm * 1000 + a.gn; }
@@ -866,11 +892,12 @@ extern "C" int mz_op_conv(int dtype, int kind, const void* in0, const void* in1,
         case 3: plan_conv(c, dtype, MODE_GEMM1, cout, 2 * cout, 1, 1, OUT_PLAIN, SRC_CONCAT, cout, cout); break;
         default: return fail(MZ_ERR_INVALID_ARGUMENT, "bad op kind %d", kind);
     }
-    TempBuf zero, packed;
+    TempBuf zero, packed, packed16;
     HIPCHK(hipMalloc(&zero.p, 4096));
     HIPCHK(hipMemsetAsync(zero.p, 0, 4096, s));
     rc = pack_conv(c, dtype, w_dev_f32, s);
     packed.p = c.packed;
+    packed16.p = c.packed16;
     if (rc) return rc;
     // a throw-away handle carries the zero page / staging choice for Runner
     mz_handle fake;
@@ -917,11 +944,12 @@ extern "C" int mz_op_final(int dtype, const void* feat, const void* img, const f
     hipStream_t s = (hipStream_t)hip_stream;
     ConvW c;
     plan_conv(c, dtype, MODE_CONV3, 12, cin, 3, 3, OUT_FINAL, SRC_PLAIN, 0, 0);
-    TempBuf zero, packed;
+    TempBuf zero, packed, packed16;
     HIPCHK(hipMalloc(&zero.p, 4096));
     HIPCHK(hipMemsetAsync(zero.p, 0, 4096, s));
     rc = pack_conv(c, dtype, w_dev_f32, s);
     packed.p = c.packed;
+    packed16.p = c.packed16;
     if (rc) return rc;
     mz_handle fake;
     fake.zero_page = zero.p;

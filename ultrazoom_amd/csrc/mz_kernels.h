@@ -65,6 +65,9 @@ struct ConvArgs {
     int clamp;
     int io_u8;         // EPI_FINAL: img and out are uint8 images (scaled by 1/255 on read, x255 + 0.5 on write)
     int persist;       // > 0: launch the persistent wide 3x3 kernel with this many workgroups (a multiple of 8)
+    int s16;           // persistent launches of 16-bit types: use the 16x16x32-MFMA kernel (needs wpk16)
+    const void* wpk16; // weights packed for it: [ntile][32-channel chunk][tap][2*nt][64 lanes][16 B]
+    int nchunks16;     // 32-channel chunks
     int use_glds;      // stage through global_load_lds (1) or through registers (0)
     unsigned long long* dbg;  // -DMZ_STAMP diagnostic builds: per-stage s_memtime stamps of one workgroup
 };
@@ -88,9 +91,11 @@ struct PackArgs {
     int out_map;       // OutMap
     int cq, cq_p;      // D2S: real / padded channels per output pixel
     int in_map;        // SrcKind
+    int frag16;        // 1: fragments of the 16x16x32 MFMA (16 channels x 32 K; 16-bit types, SRC_PLAIN only); nchunks counts 32-channel chunks
     int c0, cp0, c1;   // CONCAT: real/padded channels of in0, real channels of in1;  PLAIN/CRUSH: c0 = cin, cp0 = padded cin
 };
 size_t packed_bytes(int taps, int nt, int ntiles, int nchunks);
+size_t conv16_lds_bytes(int mode, int nt);
 hipError_t launch_pack(const PackArgs& a, hipStream_t s);
 
 // ---- small kernels ----------------------------------------------------------------------------

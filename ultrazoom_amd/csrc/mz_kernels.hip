@@ -172,6 +172,16 @@ template <class TT> __device__ __forceinline__ void st_unit(void* p, const float
 
 template <class TT> __device__ __forceinline__ void mma(f32x16& acc, const u32x4& w, const u32x4& x);
 template <> __device__ __forceinline__ void mma<TBF16>(f32x16& acc, const u32x4& w, const u32x4& x) {
+#if defined(MZ_ABLATE) && (MZ_ABLATE & 128)
+    // timing-only (WRONG results): the same FLOPs as two v_mfma_f32_16x16x32_bf16, to price that shape's clock in situ
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    f32x4_ q0 = __builtin_shufflevector(acc, acc, 0, 1, 2, 3), q1 = __builtin_shufflevector(acc, acc, 4, 5, 6, 7);
+    q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x), q0, 0, 0, 0);
+    q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x), q1, 0, 0, 0);
+    acc[0] = q0[0]; acc[1] = q0[1]; acc[2] = q0[2]; acc[3] = q0[3];
+    acc[4] = q1[0]; acc[5] = q1[1]; acc[6] = q1[2]; acc[7] = q1[3];
+    return;
+#endif
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x),
                                                   acc, 0, 0, 0);
 }
@@ -360,11 +370,13 @@ __device__ __forceinline__ void run_items(f32x16 (&acc)[2][NT], Frags<NT>& cur, 
 // ================================================================================================
 // x / d for 0 <= x < 2^24 with a host-provided 1.0f / d: a handful of instructions instead of the ~30 of a runtime
 // integer division (the tile bookkeeping below ran five of them per workgroup)
+// Every caller divides wave-uniform tile ids: the quotient is returned through readfirstlane so that it (and the
+// control flow that depends on it) stays in scalar registers although the float conversion runs on the VALU.
 __device__ __forceinline__ int fdiv(int x, int d, float inv) {
     int q = (int)((float)x * inv);
     const int r = x - q * d;
     q += (r >= d) - (r < 0);
-    return q;
+    return __builtin_amdgcn_readfirstlane(q);
 }
 
 // logical id -> tile (the group walk)
@@ -1021,7 +1033,7 @@ __global__ __launch_bounds__(640) void conv3p_kernel(const ConvArgs a) {
     const int cnt = q + (xcd < rem ? 1 : 0);
     const int base = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
     // first valid (non-padding) tile at or after list position i; cnt when the list is exhausted
-    auto seek = [&](int i, int& mtile, int& ntile) {
+    auto seek = [&](int i, int& mtile, int& ntile) __attribute__((always_inline)) {
         while (i < cnt && !tile_of(a, base + i, mtile, ntile)) i += step;
         return i;
     };
@@ -1030,7 +1042,7 @@ __global__ __launch_bounds__(640) void conv3p_kernel(const ConvArgs a) {
     if (cur >= cnt) return;  // uniform over the workgroup
 
     const int tpi = a.tiles_x * a.tiles_y;
-    auto tile_origin = [&](int mt, int& b, int& y0, int& x0) {
+    auto tile_origin = [&](int mt, int& b, int& y0, int& x0) __attribute__((always_inline)) {
         b = fdiv(mt, tpi, a.inv_tpi);
         const int trem = mt - b * tpi;
         const int tyi = fdiv(trem, a.tiles_x, a.inv_tiles_x);
@@ -1052,7 +1064,7 @@ __global__ __launch_bounds__(640) void conv3p_kernel(const ConvArgs a) {
         bool l_ok = true;
         if (w == 9) {
             const char* wsrc = (const char*)a.wpk + (size_t)ntile * nstages * B_SLOT + lane * 16;
-            auto issue = [&]() {
+            auto issue = [&]() __attribute__((always_inline)) {
                 if (!l_ok) return;
                 const char* src = wsrc + (size_t)l_st * B_SLOT;
                 char* dst = smem + l_slot * SLOT + A_SLOT;
@@ -1080,7 +1092,7 @@ __global__ __launch_bounds__(640) void conv3p_kernel(const ConvArgs a) {
             // halo image: instruction j covers entries [64 j, 64 j + 64); per-lane byte offsets inside image b
             uint32_t aoff[A_INSTR];
             const char* img = nullptr;
-            auto set_tile = [&](int mt) {
+            auto set_tile = [&](int mt) __attribute__((always_inline)) {
                 int b, y0, x0;
                 tile_origin(mt, b, y0, x0);
                 img = (const char*)a.in0 + (long long)b * a.p0 * plane_in;
@@ -1096,7 +1108,7 @@ __global__ __launch_bounds__(640) void conv3p_kernel(const ConvArgs a) {
                 }
             };
             set_tile(mtile);
-            auto issue = [&]() {
+            auto issue = [&]() __attribute__((always_inline)) {
                 if (!l_ok) return;
                 const char* src = img + 2LL * l_st * plane_in;
                 char* dst = smem + l_slot * SLOT;
@@ -1165,6 +1177,390 @@ __global__ __launch_bounds__(640) void conv3p_kernel(const ConvArgs a) {
         if (a.epi == EPI_D2S) store_epilogue<TT, NT, true, EPI_D2S, false>(a, acc, lane, nbase, b, ey, ex, em);
         else if (a.silu) store_epilogue<TT, NT, true, EPI_STORE, true>(a, acc, lane, nbase, b, ey, ex, em);
         else store_epilogue<TT, NT, true, EPI_STORE, false>(a, acc, lane, nbase, b, ey, ex, em);
+        cur = seek(cur + step, mtile, ntile);
+    }
+}
+
+// ================================================================================================
+// 3x3 convolution on v_mfma_f32_16x16x32_{bf16,f16}, persistent (16-bit types only).
+// Why a second MFMA shape: the chip is power-limited in this loop and holds a visibly higher clock
+// on the 16x16x32 shape than on 32x32x16 at identical FLOPs, LDS bytes and staging traffic.
+//   * K-step of one MFMA = 32 channels = FOUR 16-byte planes: lane (g, c) = (lane >> 4, lane & 15) supplies plane g
+//     of pixel c (B operand) / of output channel c (A operand); it receives channels 4g..4g+3 of pixel c.
+//   * wave tile as before: 64 pixels x BN channels = 4 pixel fragments x 2*NT channel fragments (96 accumulator regs).
+//   * a 32-channel K-stage with all 9 taps would need 94 KB per ring slot, so the two operands turn on separate
+//     rings: the halo image (4 planes, 40 KB) is double-buffered per 32-channel chunk, the weights stream in
+//     tap-ROW sub-stages (3 taps x 2*NT fragments = 18 KB) through 3 slots; one barrier per sub-stage.  With three
+//     sub-stages per chunk the weight slot of a sub-stage is simply its tap row.
+//   * loaders / persistence / tile walk exactly as conv3p_kernel.
+//   * inside a sub-stage the fragments are software-pipelined per GROUP of 8 MFMAs (two channel fragments x four
+//     pixel fragments): the next group's 2 weight fragments and a share of the next tap's 4 pixel fragments are
+//     requested in the shadow of the group's first MFMAs.
+// ================================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <class TT> __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& w, const u32x4& x);
+template <> __device__ __forceinline__ void mma16<TBF16>(f32x4& acc, const u32x4& w, const u32x4& x) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16<TF16>(f32x4& acc, const u32x4& w, const u32x4& x) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, w), __builtin_bit_cast(f16x8_t, x), acc, 0, 0, 0);
+}
+struct Frag16 {
+    u32x4 x[2][4];  // [tap parity][pixel fragment]
+    u32x4 w[3][2];  // [group % 3][channel fragment of the group]: requested TWO groups ahead
+};
+// LDS reads return in order, so lgkmcnt(N) = "everything but the N youngest reads has landed" (no scalar load is in
+// flight inside the K loop: its straight-line code uses no kernel argument).  The registers named "+v" are the
+// ones the following MFMAs may use; the N youngest stay untouched until a later wait.
+template <int N> __device__ __forceinline__ void wait_w16(u32x4& w0, u32x4& w1) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(w0), "+v"(w1) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_wx16(u32x4& w0, u32x4& w1, u32x4& x0, u32x4& x1, u32x4& x2, u32x4& x3) {
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(w0), "+v"(w1), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "n"(N) : "memory");
+}
+// byte offset of pixel fragment pf of tap (dy, dx) inside one plane of the halo image, relative to the wave's first row
+template <int MODE, int DY, int DX, int PF> constexpr int s16_a_off() {
+    using G = Geo<MODE>;
+    return G::ROW_PER_WAVE == 2 ? ((DY + (PF >> 1)) * G::ROWW + DX + 16 * (PF & 1)) * 16 : (DY * G::ROWW + DX + 16 * PF) * 16;
+}
+// Group S = (tap t, channel-fragment pair n) = 8 MFMAs.  While it runs it requests the weight pair of group S + 2 and
+// its share of the NEXT tap's pixel fragments (NT = 3: two each in groups 0 and 1; NT = 2: all four in group 0;
+// NT = 1: all four, one tap ahead only).  Tap t uses pixel buffer t & 1.
+// The LAST group of a sub-stage requests the weight pairs of the NEXT sub-stage's groups 0 and 1, and right after its
+// last MFMA the next sub-stage's tap-0 pixel fragments (into buffer 0, which tap 2 has just finished with): the
+// loaders guarantee a sub-stage's data one barrier early, so these reads fly across the barrier instead of being
+// waited for behind it.
+template <int NT, int S> struct S16Plan {
+    static constexpr int NSTEP = 3 * NT;
+    static constexpr int t = S / NT, n = S % NT;
+    static constexpr bool last = S == NSTEP - 1;
+    static constexpr bool w_issue = S + 2 < NSTEP;
+    static constexpr int x_count = t + 1 < 3 ? (NT == 3 ? (n < 2 ? 2 : 0) : (n == 0 ? 4 : 0)) : 0;
+    static constexpr int x_first = NT == 3 ? 2 * n : 0;
+    static constexpr int issued = (w_issue ? 2 : 0) + x_count;  // reads requested during this group
+    // everything requested BEFORE this group has landed once at most `issued` reads are outstanding; NT = 1 needs the
+    // pixel fragments it has just requested right away
+    static constexpr int allow = NT == 1 ? (w_issue ? 2 : 0) : issued;
+};
+// first fragments of a sub-stage (tap row DY): R = 0..3 weight pairs of groups 0 and 1, R = 4..7 pixel fragments of tap 0
+template <int NT, int MODE, int DY, int R>
+__device__ __forceinline__ void s16_first_read(Frag16& f, uint32_t a_addr, uint32_t b_addr) {
+    constexpr int NF = 2 * NT;
+    if constexpr (R < 2) f.w[0][R] = lds_read128<R * 1024>(b_addr);
+    else if constexpr (R < 4) f.w[1][R - 2] = lds_read128<((1 / NT) * NF + 2 * (1 % NT) + (R - 2)) * 1024>(b_addr);
+    else f.x[0][R - 4] = lds_read128<s16_a_off<MODE, DY, 0, R - 4>()>(a_addr);
+}
+template <class TT, int NT, int MODE, int DY, bool FIN, int S, int M>
+__device__ __forceinline__ void s16_mfmas(f32x4 (&acc)[4][2 * NT], Frag16& f, uint32_t a_addr, uint32_t b_addr, uint32_t b_next) {
+    if constexpr (M < 8) {
+        using P = S16Plan<NT, S>;
+        constexpr int NF = 2 * NT;
+        constexpr int t = P::t, n = P::n, xp = t & 1, wp = S % 3;
+        constexpr int k = M >> 2, pf = M & 3;
+        mma16<TT>(acc[pf][2 * n + k], f.w[wp][k], f.x[xp][pf]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (P::w_issue && M < 2) {
+            constexpr int t2 = (S + 2) / NT, n2 = (S + 2) % NT;
+            f.w[(S + 2) % 3][M] = lds_read128<(t2 * NF + 2 * n2 + M) * 1024>(b_addr);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (M >= 2 && M - 2 < P::x_count) {
+            constexpr int pfn = P::x_first + M - 2;
+            f.x[xp ^ 1][pfn] = lds_read128<s16_a_off<MODE, DY, t + 1, pfn>()>(a_addr);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (P::last && !FIN && M < 4) {  // w[0] / w[1] were last used by groups NSTEP-3 / NSTEP-2
+            s16_first_read<NT, MODE, (DY + 1) % 3, M>(f, a_addr, b_next);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        s16_mfmas<TT, NT, MODE, DY, FIN, S, M + 1>(acc, f, a_addr, b_addr, b_next);
+    }
+}
+template <class TT, int NT, int MODE, int DY, bool FIN, int S>
+__device__ __forceinline__ void s16_steps(f32x4 (&acc)[4][2 * NT], Frag16& f, uint32_t a_addr, uint32_t b_addr, uint32_t b_next) {
+    if constexpr (S < 3 * NT) {
+        using P = S16Plan<NT, S>;
+        __builtin_amdgcn_sched_barrier(0);
+        s16_mfmas<TT, NT, MODE, DY, FIN, S, 0>(acc, f, a_addr, b_addr, b_next);
+        if constexpr (S + 1 < 3 * NT) {
+            constexpr int wn = (S + 1) % 3, xn = ((S + 1) / NT) & 1;
+            if constexpr ((S + 1) % NT == 0)  // the next group starts a new tap: its pixel fragments must be in
+                wait_wx16<P::allow>(f.w[wn][0], f.w[wn][1], f.x[xn][0], f.x[xn][1], f.x[xn][2], f.x[xn][3]);
+            else
+                wait_w16<P::allow>(f.w[wn][0], f.w[wn][1]);
+        }
+        s16_steps<TT, NT, MODE, DY, FIN, S + 1>(acc, f, a_addr, b_addr, b_next);
+    }
+}
+// one tap row of one 32-channel chunk.  Its first fragments were requested by the previous sub-stage (or by
+// s16_prime).  a_next: the halo image the NEXT sub-stage reads (the other slot after tap row 2).
+// FIN: the tile's last sub-stage -- the epilogue follows, so the next tile's first fragments are requested after it
+// (s16_prime) instead of being kept alive across it.
+template <class TT, int NT, int MODE, int DY, bool FIN>
+__device__ __forceinline__ void s16_substage(f32x4 (&acc)[4][2 * NT], Frag16& f, uint32_t a_addr, uint32_t b_addr,
+                                             uint32_t a_next, uint32_t b_next) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f.w[0][0]), "+v"(f.w[0][1]), "+v"(f.w[1][0]), "+v"(f.w[1][1]), "+v"(f.x[0][0]), "+v"(f.x[0][1]),
+                   "+v"(f.x[0][2]), "+v"(f.x[0][3])::"memory");
+    s16_steps<TT, NT, MODE, DY, FIN, 0>(acc, f, a_addr, b_addr, b_next);
+    if constexpr (!FIN) {
+        __builtin_amdgcn_sched_barrier(0);
+        s16_first_read<NT, MODE, (DY + 1) % 3, 4>(f, a_next, b_next);
+        s16_first_read<NT, MODE, (DY + 1) % 3, 5>(f, a_next, b_next);
+        s16_first_read<NT, MODE, (DY + 1) % 3, 6>(f, a_next, b_next);
+        s16_first_read<NT, MODE, (DY + 1) % 3, 7>(f, a_next, b_next);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// the three tap rows of one 32-channel chunk; advances the ring pointers
+template <class TT, int NT, int MODE, bool FIN, int B_SLOT>
+__device__ __forceinline__ void s16_chunk(f32x4 (&acc)[4][2 * NT], Frag16& f, uint32_t& a_cur, uint32_t& a_oth, uint32_t& b_cur,
+                                          const uint32_t b_end) {
+    uint32_t bn = b_cur + B_SLOT;
+    bn = bn >= b_end ? bn - 4 * B_SLOT : bn;
+    __builtin_amdgcn_s_barrier();
+    s16_substage<TT, NT, MODE, 0, false>(acc, f, a_cur, b_cur, a_cur, bn);
+    b_cur = bn; bn = b_cur + B_SLOT; bn = bn >= b_end ? bn - 4 * B_SLOT : bn;
+    __builtin_amdgcn_s_barrier();
+    s16_substage<TT, NT, MODE, 1, false>(acc, f, a_cur, b_cur, a_cur, bn);
+    b_cur = bn; bn = b_cur + B_SLOT; bn = bn >= b_end ? bn - 4 * B_SLOT : bn;
+    __builtin_amdgcn_s_barrier();
+    s16_substage<TT, NT, MODE, 2, FIN>(acc, f, a_cur, b_cur, a_oth, bn);
+    b_cur = bn;
+    const uint32_t tmp = a_cur; a_cur = a_oth; a_oth = tmp;
+}
+template <int NT, int MODE> __device__ __forceinline__ void s16_prime(Frag16& f, uint32_t a_addr, uint32_t b_addr) {
+    s16_first_read<NT, MODE, 0, 0>(f, a_addr, b_addr);
+    s16_first_read<NT, MODE, 0, 1>(f, a_addr, b_addr);
+    s16_first_read<NT, MODE, 0, 2>(f, a_addr, b_addr);
+    s16_first_read<NT, MODE, 0, 3>(f, a_addr, b_addr);
+    s16_first_read<NT, MODE, 0, 4>(f, a_addr, b_addr);
+    s16_first_read<NT, MODE, 0, 5>(f, a_addr, b_addr);
+    s16_first_read<NT, MODE, 0, 6>(f, a_addr, b_addr);
+    s16_first_read<NT, MODE, 0, 7>(f, a_addr, b_addr);
+}
+
+// accumulators -> plane-major tensor.  Lane (g, c) holds channels 4g..4g+3 of pixel c of each 16-channel fragment;
+// v_permlane16_swap between the two fragments of a group leaves lane g with one full 16-byte plane entry:
+// fragment (g & 1) of the pair, plane (g >> 1) of that fragment.
+template <class TT, int NT, int MODE, int EPI, bool SILU>
+__device__ __forceinline__ void store_epilogue16(const ConvArgs& a, f32x4 (&acc)[4][2 * NT], int lane, int w, int nbase, int b,
+                                                 int y0, int x0) {
+    using G = Geo<MODE>;
+    constexpr bool d2s = EPI == EPI_D2S;
+    const int g = lane >> 4, c = lane & 15;
+    const long long plane_o = d2s ? (long long)a.Hout * a.Wout * 16 : (long long)a.H * a.W * 16;
+    char* const obase = (char*)a.out + (long long)b * a.p_out * plane_o;
+#pragma unroll
+    for (int pf = 0; pf < 4; ++pf) {
+        const int py = G::ROW_PER_WAVE == 2 ? y0 + 2 * w + (pf >> 1) : y0 + w;
+        const int px = G::ROW_PER_WAVE == 2 ? x0 + 16 * (pf & 1) + c : x0 + 16 * pf + c;
+        const bool inside = py < a.H && px < a.W;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float ea = acc[pf][2 * n][j], eb = acc[pf][2 * n + 1][j];
+                const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, ea), __builtin_bit_cast(uint32_t, eb),
+                                                                 false, false);
+                const uint32_t s0 = sw[0], s1 = sw[1];
+                v[j] = __builtin_bit_cast(float, s0);
+                v[4 + j] = __builtin_bit_cast(float, s1);
+            }
+            const int cu = 2 * (2 * n + (g & 1)) + (g >> 1);  // 16-byte unit inside this workgroup's BN channels
+            const int nch = nbase + cu * 8;
+            if constexpr (SILU) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = v[j] * sigmoidf_(v[j]);
+            }
+            if (!inside) continue;
+            char* dst;
+            if constexpr (d2s) {
+                if (nch >= 4 * a.cp_out) continue;
+                const int ij = nch / a.cp_out;
+                const int ch = nch - ij * a.cp_out;
+                const int Y = 2 * py + (ij >> 1), X = 2 * px + (ij & 1);
+                dst = obase + (ch >> 3) * plane_o + ((long long)Y * a.Wout + X) * 16;
+            } else {
+                if (nch >= a.cp_out) continue;
+                dst = obase + (nch >> 3) * plane_o + ((long long)py * a.W + px) * 16;
+            }
+            st_unit<TT>(dst, v);
+        }
+    }
+}
+
+template <class TT, int NT, int MODE>
+__global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
+    using G = Geo<MODE>;
+    constexpr int NF = 2 * NT;
+    constexpr int BN = 32 * NT;
+    constexpr int A_PLANE = G::PLANE;
+    constexpr int A_SLOT = 4 * A_PLANE;
+    constexpr int A_INSTR = 4 * G::PLANE_ENT / 64;
+    constexpr int B_PIECES = 3 * NF;
+    constexpr int B_SLOT = B_PIECES * 1024;
+    constexpr int B_BASE = 2 * A_SLOT;  // LDS: [halo 0][halo 1][weights 0..3]
+    static_assert(3 * B_PIECES < 64 && A_INSTR < 64, "vmcnt is a 6-bit counter");
+    static_assert((4 * G::PLANE_ENT) % 64 == 0, "halo image = whole DMA instructions");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7 compute, 8 = halo loader, 9 = weight loader
+    const int nchunks = a.nchunks16;                          // 32-channel chunks
+
+    const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3, step = gridDim.x >> 3;
+    const int q = a.grid >> 3, rem = a.grid & 7;
+    const int cnt = q + (xcd < rem ? 1 : 0);
+    const int base = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+    auto seek = [&](int i, int& mtile, int& ntile) __attribute__((always_inline)) {
+        while (i < cnt && !tile_of(a, base + i, mtile, ntile)) i += step;
+        return i;
+    };
+    int mtile = 0, ntile = 0;
+    int cur = seek(pos, mtile, ntile);
+    if (cur >= cnt) return;  // uniform over the workgroup
+
+    const int tpi = a.tiles_x * a.tiles_y;
+    auto tile_origin = [&](int mt, int& b, int& y0, int& x0) __attribute__((always_inline)) {
+        b = fdiv(mt, tpi, a.inv_tpi);
+        const int trem = mt - b * tpi;
+        const int tyi = fdiv(trem, a.tiles_x, a.inv_tiles_x);
+        y0 = tyi * G::TH;
+        x0 = (trem - tyi * a.tiles_x) * G::TW;
+    };
+
+    if (w >= 8) {
+        int ntl = 0;
+        {
+            int mt_, nt_;
+            for (int i = cur; i < cnt; i = seek(i + step, mt_, nt_)) ++ntl;
+        }
+        const int total = ntl * nchunks * 3;  // sub-stages = barriers
+        int l_pos = cur;
+        bool l_ok = true;
+        if (w == 9) {
+            // ---- weight loader: a linear stream of 3 * nchunks sub-stages per tile through a 4-slot ring, three
+            //      sub-stages ahead; at barrier u it guarantees sub-stage u + 1 (whose first fragments the compute
+            //      waves request before barrier u + 1) ----
+            const int nsub = 3 * nchunks;
+            const char* wsrc = (const char*)a.wpk16 + (size_t)ntile * nsub * B_SLOT + lane * 16;
+            int l_u = 0, l_slot = 0, issued = 0;
+            auto issue = [&]() __attribute__((always_inline)) {
+                if (!l_ok) return;
+                const char* src = wsrc + (size_t)l_u * B_SLOT;
+                char* dst = smem + B_BASE + l_slot * B_SLOT;
+#pragma unroll
+                for (int j = 0; j < B_PIECES; ++j) glds16(src + j * 1024, dst + j * 1024);
+                ++issued;
+                l_slot = (l_slot + 1) & 3;
+                if (++l_u == nsub) {
+                    l_u = 0;
+                    int mt_, nt_ = 0;
+                    l_pos = seek(l_pos + step, mt_, nt_);
+                    l_ok = l_pos < cnt;
+                    wsrc = (const char*)a.wpk16 + (size_t)nt_ * nsub * B_SLOT + lane * 16;
+                }
+            };
+            issue();
+            issue();
+            issue();
+            // start-up barrier: sub-stage 0 has landed
+            if (issued >= 3) wait_vmcnt<2 * B_PIECES>(); else if (issued == 2) wait_vmcnt<B_PIECES>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            for (int u = 0; u < total; ++u) {
+                // sub-stage u + 1 has landed once only the sub-stages issued after it are outstanding
+                if (issued >= u + 3) wait_vmcnt<B_PIECES>(); else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                issue();  // sub-stage u + 3 -> the slot of u - 1
+            }
+        } else {
+            // ---- halo loader: one 4-plane image per 32-channel chunk, one chunk ahead ----
+            const long long plane_in = (long long)a.H * a.W * 16;
+            uint32_t aoff[A_INSTR];
+            unsigned long long hi_planes = 0;  // bit j: instruction j's entry of this lane lies in plane 2 or 3
+#pragma unroll
+            for (int j = 0; j < A_INSTR; ++j)
+                if ((64 * j + lane) / G::PLANE_ENT >= 2) hi_planes |= 1ull << j;
+            const char* img = nullptr;
+            auto set_tile = [&](int mt) __attribute__((always_inline)) {
+                int b, y0, x0;
+                tile_origin(mt, b, y0, x0);
+                img = (const char*)a.in0 + (long long)b * a.p0 * plane_in;
+#pragma unroll
+                for (int j = 0; j < A_INSTR; ++j) {
+                    const int e = 64 * j + lane;
+                    const int plane = e / G::PLANE_ENT;
+                    const int p = e - plane * G::PLANE_ENT;
+                    const int py = p / G::ROWW, px = p - py * G::ROWW;
+                    const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+                    const bool ok = (p < G::NPIX) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                    aoff[j] = ok ? (uint32_t)(((plane * a.H + gy) * a.W + gx) * 16) : 0xffffffffu;
+                }
+            };
+            set_tile(mtile);
+            int l_kc = 0, l_slot = 0;
+            auto issue = [&]() __attribute__((always_inline)) {
+                if (!l_ok) return;
+                const char* src = img + 4LL * l_kc * plane_in;
+                const bool half = 4 * l_kc + 2 >= a.p0;  // the tensor ends after this chunk's first two planes
+                char* dst = smem + l_slot * A_SLOT;
+#pragma unroll
+                for (int j = 0; j < A_INSTR; ++j) {
+                    const bool zero = aoff[j] == 0xffffffffu || (half && ((hi_planes >> j) & 1));
+                    glds16(zero ? (const char*)a.zero : src + aoff[j], dst + j * 1024);
+                }
+                l_slot ^= 1;
+                if (++l_kc == nchunks) {
+                    l_kc = 0;
+                    int mt_ = 0, nt_;
+                    l_pos = seek(l_pos + step, mt_, nt_);
+                    l_ok = l_pos < cnt;
+                    if (l_ok) set_tile(mt_);
+                }
+            };
+            issue();
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();  // start-up barrier: chunk 0 has landed
+            int dy = 0;
+            for (int u = 0; u < total; ++u) {
+                if (dy == 2) wait_vmcnt<0>();  // the next chunk is complete one barrier before its first sub-stage
+                __builtin_amdgcn_s_barrier();
+                if (dy == 0) issue();          // chunk c + 1 -> the slot chunk c - 1 was read from
+                dy = dy == 2 ? 0 : dy + 1;
+            }
+        }
+        return;
+    }
+
+    // ------------------------- compute waves -------------------------
+    const int g = lane >> 4, c = lane & 15;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t a_lane = lds_base + g * A_PLANE + ((G::ROW_PER_WAVE * w) * G::ROWW + c) * 16;
+    const uint32_t b_lane = lds_base + B_BASE + lane * 16;
+    uint32_t a_cur = a_lane, a_oth = a_lane + A_SLOT;  // this lane's address in the current / the other halo image
+    uint32_t b_cur = b_lane;                           // ... and in the current weight slot
+    const uint32_t b_end = b_lane + 4 * B_SLOT;
+    Frag16 f;
+    __builtin_amdgcn_s_barrier();  // start-up barrier: chunk 0 and weight sub-stage 0 have landed
+    s16_prime<NT, MODE>(f, a_lane, b_lane);
+    while (cur < cnt) {
+        int b, y0, x0;
+        tile_origin(mtile, b, y0, x0);
+        f32x4 acc[4][NF];
+#pragma unroll
+        for (int pf = 0; pf < 4; ++pf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) acc[pf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kc = 0; kc + 1 < nchunks; ++kc) s16_chunk<TT, NT, MODE, false, B_SLOT>(acc, f, a_cur, a_oth, b_cur, b_end);
+        s16_chunk<TT, NT, MODE, true, B_SLOT>(acc, f, a_cur, a_oth, b_cur, b_end);
+        const int nbase = ntile * BN;
+        if (a.epi == EPI_D2S) store_epilogue16<TT, NT, MODE, EPI_D2S, false>(a, acc, lane, w, nbase, b, y0, x0);
+        else if (a.silu) store_epilogue16<TT, NT, MODE, EPI_STORE, true>(a, acc, lane, w, nbase, b, y0, x0);
+        else store_epilogue16<TT, NT, MODE, EPI_STORE, false>(a, acc, lane, w, nbase, b, y0, x0);
+        s16_prime<NT, MODE>(f, a_cur, b_cur);  // the next tile's first fragments (guaranteed since the last barrier)
         cur = seek(cur + step, mtile, ntile);
     }
 }
@@ -1345,6 +1741,12 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
     }
 }
 
+// the 16x16x32 kernel: two 4-plane halo images + four tap-row weight slots
+size_t conv16_lds_bytes(int mode, int nt) {
+    const size_t a_slot = 4 * (size_t)(mode == MODE_C3W16 ? 640 : 672) * 16;
+    return 2 * a_slot + 4 * (size_t)(3 * 2 * nt * 1024);
+}
+
 size_t conv_lds_bytes(int mode, int nt) {
     if (mode == MODE_C3W16 || mode == MODE_C3W8) {
         const int a_slot = (mode == MODE_C3W16 ? 2 * 640 : 2 * 672) * 16;
@@ -1383,7 +1785,12 @@ template <class TT, int NT, int MODE> static hipError_t launch_one(const ConvArg
         if constexpr (NT <= 3) {
             if (a.epi == EPI_FUSEDMIX)
                 hipLaunchKernelGGL((conv3w_kernel<TT, NT, MODE, true>), dim3(a.grid), dim3(576), lds, s, a);
-            else if (a.persist > 0 && (a.epi == EPI_STORE || a.epi == EPI_D2S))
+            else if (a.persist > 0 && a.s16 && (a.epi == EPI_STORE || a.epi == EPI_D2S)) {
+                if constexpr (TT::SZ == 2)
+                    hipLaunchKernelGGL((conv3s_kernel<TT, NT, MODE>), dim3(a.persist), dim3(640), conv16_lds_bytes(MODE, NT), s, a);
+                else
+                    return hipErrorInvalidValue;
+            } else if (a.persist > 0 && (a.epi == EPI_STORE || a.epi == EPI_D2S))
                 hipLaunchKernelGGL((conv3p_kernel<TT, NT, MODE>), dim3(a.persist), dim3(640), lds, s, a);
             else
                 hipLaunchKernelGGL((conv3w_kernel<TT, NT, MODE, false>), dim3(a.grid), dim3(576), lds, s, a);
@@ -1432,6 +1839,11 @@ template <class TT, int NT, int MODE> static hipError_t set_lds_one() {
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute((const void*)conv3p_kernel<TT, NT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return e;
+        if constexpr (TT::SZ == 2) {
+            e = hipFuncSetAttribute((const void*)conv3s_kernel<TT, NT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)conv16_lds_bytes(MODE, NT));
+            if (e != hipSuccess) return e;
+        }
         return hipFuncSetAttribute((const void*)conv3w_kernel<TT, NT, MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    bytes);
     } else {
@@ -1468,13 +1880,15 @@ template <class TT> __global__ void pack_kernel(const PackArgs a, long long tota
     long long t = idx;
     const int e = (int)(t % EPL); t /= EPL;
     const int lane = (int)(t % 64); t /= 64;
-    const int nt = (int)(t % a.nt); t /= a.nt;
+    const int nfr = a.frag16 ? 2 * a.nt : a.nt;  // fragments per tap: 16-channel (16x16x32 MFMA) or 32-channel ones
+    const int nt = (int)(t % nfr); t /= nfr;
     const int tap = (int)(t % a.taps); t /= a.taps;
     const int kc = (int)(t % a.nchunks); t /= a.nchunks;
     const int nb = (int)t;
-    const int n = (nb * a.nt + nt) * 32 + (lane & 31);
+    const int n = a.frag16 ? (nb * nfr + nt) * 16 + (lane & 15) : (nb * a.nt + nt) * 32 + (lane & 31);
     const int hh = lane >> 5;
-    const int kin = hh * (CK / 2) + e;  // channel within the chunk
+    const int kin = a.frag16 ? (lane >> 4) * 8 + e : hh * (CK / 2) + e;  // channel within the chunk
+    const int ckk = a.frag16 ? 32 : CK;                                  // channels per chunk
 
     // output channel
     int o = -1;
@@ -1490,7 +1904,7 @@ template <class TT> __global__ void pack_kernel(const PackArgs a, long long tota
     // input channel and filter tap
     int ci = -1, ty = 0, tx = 0;
     if (a.in_map == SRC_PLAIN) {
-        const int k = kc * CK + kin;
+        const int k = kc * ckk + kin;
         ci = k < a.c0 ? k : -1;
         ty = tap / a.kw;
         tx = tap - ty * a.kw;
@@ -1530,7 +1944,7 @@ size_t packed_bytes(int taps, int nt, int ntiles, int nchunks) {
 
 hipError_t launch_pack(const PackArgs& a, hipStream_t s) {
     const int sz = dtype_size(a.dtype);
-    const long long total = (long long)packed_bytes(a.taps, a.nt, a.ntiles, a.nchunks) / sz;
+    const long long total = (long long)packed_bytes(a.taps, a.frag16 ? 2 * a.nt : a.nt, a.ntiles, a.nchunks) / sz;
     const int blocks = (int)((total + 255) / 256);
     switch (a.dtype) {
         case DT_F32: hipLaunchKernelGGL(pack_kernel<TF32>, dim3(blocks), dim3(256), 0, s, a, total); break;
