@@ -1219,125 +1219,98 @@ template <int N> __device__ __forceinline__ void wait_wx16(u32x4& w0, u32x4& w1,
     asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(w0), "+v"(w1), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "n"(N) : "memory");
 }
 // byte offset of pixel fragment pf of tap (dy, dx) inside one plane of the halo image, relative to the wave's first row
-template <int MODE, int DY, int DX, int PF> constexpr int s16_a_off() {
+template <int MODE, int TAP, int PF> constexpr int s16_a_off() {
     using G = Geo<MODE>;
+    constexpr int DY = TAP / 3, DX = TAP % 3;
     return G::ROW_PER_WAVE == 2 ? ((DY + (PF >> 1)) * G::ROWW + DX + 16 * (PF & 1)) * 16 : (DY * G::ROWW + DX + 16 * PF) * 16;
 }
-// Group S = (tap t, channel-fragment pair n) = 8 MFMAs.  While it runs it requests the weight pair of group S + 2 and
-// its share of the NEXT tap's pixel fragments (NT = 3: two each in groups 0 and 1; NT = 2: all four in group 0;
-// NT = 1: all four, one tap ahead only).  Tap t uses pixel buffer t & 1.
-// The LAST group of a sub-stage requests the weight pairs of the NEXT sub-stage's groups 0 and 1, and right after its
-// last MFMA the next sub-stage's tap-0 pixel fragments (into buffer 0, which tap 2 has just finished with): the
-// loaders guarantee a sub-stage's data one barrier early, so these reads fly across the barrier instead of being
-// waited for behind it.
-template <int NT, int S> struct S16Plan {
-    static constexpr int NSTEP = 3 * NT;
-    static constexpr int t = S / NT, n = S % NT;
-    static constexpr bool last = S == NSTEP - 1;
-    static constexpr bool w_issue = S + 2 < NSTEP;
-    static constexpr int x_count = t + 1 < 3 ? (NT == 3 ? (n < 2 ? 2 : 0) : (n == 0 ? 4 : 0)) : 0;
+// A 32-channel chunk = 9 * NT GROUPS; group G = (tap G / NT, channel-fragment pair G % NT) = 8 MFMAs, its two weight
+// fragments are pieces 2G, 2G+1 of the chunk's packed weights.  The chunk's weights arrive in two halves (groups
+// [0, G0) and [G0, NG), one LDS slot each), so there are two barriers per chunk -- the cadence of the 32x32x16
+// kernel's two 16-channel stages.
+// While group G runs it requests the weight pair of group G + 2 (inside the same half) and its share of the NEXT
+// tap's pixel fragments (NT = 3: two each in the tap's groups 0 and 1; NT = 2: all four in group 0; NT = 1: all
+// four, one group ahead).  Tap t uses pixel buffer t & 1; pixel fragments are prefetched across the mid-chunk barrier
+// (the halo image does not change there), weight fragments are not (the second half has just landed).
+template <int NT> struct S16Geo {
+    static constexpr int NG = 9 * NT;
+    static constexpr int G0 = (NG + 1) / 2;
+    static constexpr int B_SLOT = 2 * G0 * 1024;
+    // LDS byte offset of weight piece k of group G, relative to the weight area
+    static constexpr int w_off(int G, int k) { return G < G0 ? (2 * G + k) * 1024 : B_SLOT + (2 * (G - G0) + k) * 1024; }
+};
+template <int NT, int G, int GE> struct S16Plan {  // group G of the segment ending at GE
+    static constexpr int t = G / NT, n = G % NT;
+    static constexpr bool w_issue = G + 2 < GE;
+    static constexpr int x_count = t + 1 < 9 ? (NT == 3 ? (n < 2 ? 2 : 0) : (n == 0 ? 4 : 0)) : 0;
     static constexpr int x_first = NT == 3 ? 2 * n : 0;
     static constexpr int issued = (w_issue ? 2 : 0) + x_count;  // reads requested during this group
     // everything requested BEFORE this group has landed once at most `issued` reads are outstanding; NT = 1 needs the
     // pixel fragments it has just requested right away
     static constexpr int allow = NT == 1 ? (w_issue ? 2 : 0) : issued;
 };
-// first fragments of a sub-stage (tap row DY): R = 0..3 weight pairs of groups 0 and 1, R = 4..7 pixel fragments of tap 0
-template <int NT, int MODE, int DY, int R>
-__device__ __forceinline__ void s16_first_read(Frag16& f, uint32_t a_addr, uint32_t b_addr) {
-    constexpr int NF = 2 * NT;
-    if constexpr (R < 2) f.w[0][R] = lds_read128<R * 1024>(b_addr);
-    else if constexpr (R < 4) f.w[1][R - 2] = lds_read128<((1 / NT) * NF + 2 * (1 % NT) + (R - 2)) * 1024>(b_addr);
-    else f.x[0][R - 4] = lds_read128<s16_a_off<MODE, DY, 0, R - 4>()>(a_addr);
-}
-template <class TT, int NT, int MODE, int DY, bool FIN, int S, int M>
-__device__ __forceinline__ void s16_mfmas(f32x4 (&acc)[4][2 * NT], Frag16& f, uint32_t a_addr, uint32_t b_addr, uint32_t b_next) {
+template <class TT, int NT, int MODE, int G, int GE, int M>
+__device__ __forceinline__ void s16_mfmas(f32x4 (&acc)[4][2 * NT], Frag16& f, uint32_t a_addr, uint32_t b_addr) {
     if constexpr (M < 8) {
-        using P = S16Plan<NT, S>;
-        constexpr int NF = 2 * NT;
-        constexpr int t = P::t, n = P::n, xp = t & 1, wp = S % 3;
+        using P = S16Plan<NT, G, GE>;
+        constexpr int t = P::t, n = P::n, xp = t & 1, wp = G % 3;
         constexpr int k = M >> 2, pf = M & 3;
         mma16<TT>(acc[pf][2 * n + k], f.w[wp][k], f.x[xp][pf]);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (P::w_issue && M < 2) {
-            constexpr int t2 = (S + 2) / NT, n2 = (S + 2) % NT;
-            f.w[(S + 2) % 3][M] = lds_read128<(t2 * NF + 2 * n2 + M) * 1024>(b_addr);
+            f.w[(G + 2) % 3][M] = lds_read128<S16Geo<NT>::w_off(G + 2, M)>(b_addr);
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (M >= 2 && M - 2 < P::x_count) {
             constexpr int pfn = P::x_first + M - 2;
-            f.x[xp ^ 1][pfn] = lds_read128<s16_a_off<MODE, DY, t + 1, pfn>()>(a_addr);
+            f.x[xp ^ 1][pfn] = lds_read128<s16_a_off<MODE, t + 1, pfn>()>(a_addr);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (P::last && !FIN && M < 4) {  // w[0] / w[1] were last used by groups NSTEP-3 / NSTEP-2
-            s16_first_read<NT, MODE, (DY + 1) % 3, M>(f, a_addr, b_next);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        s16_mfmas<TT, NT, MODE, DY, FIN, S, M + 1>(acc, f, a_addr, b_addr, b_next);
+        s16_mfmas<TT, NT, MODE, G, GE, M + 1>(acc, f, a_addr, b_addr);
     }
 }
-template <class TT, int NT, int MODE, int DY, bool FIN, int S>
-__device__ __forceinline__ void s16_steps(f32x4 (&acc)[4][2 * NT], Frag16& f, uint32_t a_addr, uint32_t b_addr, uint32_t b_next) {
-    if constexpr (S < 3 * NT) {
-        using P = S16Plan<NT, S>;
+template <class TT, int NT, int MODE, int G, int GE>
+__device__ __forceinline__ void s16_groups(f32x4 (&acc)[4][2 * NT], Frag16& f, uint32_t a_addr, uint32_t b_addr) {
+    if constexpr (G < GE) {
+        using P = S16Plan<NT, G, GE>;
         __builtin_amdgcn_sched_barrier(0);
-        s16_mfmas<TT, NT, MODE, DY, FIN, S, 0>(acc, f, a_addr, b_addr, b_next);
-        if constexpr (S + 1 < 3 * NT) {
-            constexpr int wn = (S + 1) % 3, xn = ((S + 1) / NT) & 1;
-            if constexpr ((S + 1) % NT == 0)  // the next group starts a new tap: its pixel fragments must be in
+        s16_mfmas<TT, NT, MODE, G, GE, 0>(acc, f, a_addr, b_addr);
+        if constexpr (G + 1 < GE) {
+            constexpr int wn = (G + 1) % 3, xn = ((G + 1) / NT) & 1;
+            if constexpr ((G + 1) % NT == 0)  // the next group starts a new tap: its pixel fragments must be in
                 wait_wx16<P::allow>(f.w[wn][0], f.w[wn][1], f.x[xn][0], f.x[xn][1], f.x[xn][2], f.x[xn][3]);
             else
                 wait_w16<P::allow>(f.w[wn][0], f.w[wn][1]);
         }
-        s16_steps<TT, NT, MODE, DY, FIN, S + 1>(acc, f, a_addr, b_addr, b_next);
+        s16_groups<TT, NT, MODE, G + 1, GE>(acc, f, a_addr, b_addr);
     }
 }
-// one tap row of one 32-channel chunk.  Its first fragments were requested by the previous sub-stage (or by
-// s16_prime).  a_next: the halo image the NEXT sub-stage reads (the other slot after tap row 2).
-// FIN: the tile's last sub-stage -- the epilogue follows, so the next tile's first fragments are requested after it
-// (s16_prime) instead of being kept alive across it.
-template <class TT, int NT, int MODE, int DY, bool FIN>
-__device__ __forceinline__ void s16_substage(f32x4 (&acc)[4][2 * NT], Frag16& f, uint32_t a_addr, uint32_t b_addr,
-                                             uint32_t a_next, uint32_t b_next) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(f.w[0][0]), "+v"(f.w[0][1]), "+v"(f.w[1][0]), "+v"(f.w[1][1]), "+v"(f.x[0][0]), "+v"(f.x[0][1]),
-                   "+v"(f.x[0][2]), "+v"(f.x[0][3])::"memory");
-    s16_steps<TT, NT, MODE, DY, FIN, 0>(acc, f, a_addr, b_addr, b_next);
-    if constexpr (!FIN) {
-        __builtin_amdgcn_sched_barrier(0);
-        s16_first_read<NT, MODE, (DY + 1) % 3, 4>(f, a_next, b_next);
-        s16_first_read<NT, MODE, (DY + 1) % 3, 5>(f, a_next, b_next);
-        s16_first_read<NT, MODE, (DY + 1) % 3, 6>(f, a_next, b_next);
-        s16_first_read<NT, MODE, (DY + 1) % 3, 7>(f, a_next, b_next);
-        __builtin_amdgcn_sched_barrier(0);
-    }
+// first half of a chunk: a new halo image and the first weight half have just been published by the barrier
+template <class TT, int NT, int MODE>
+__device__ __forceinline__ void s16_front(f32x4 (&acc)[4][2 * NT], Frag16& f, uint32_t a_addr, uint32_t b_addr) {
+    using S = S16Geo<NT>;
+    f.x[0][0] = lds_read128<s16_a_off<MODE, 0, 0>()>(a_addr);
+    f.x[0][1] = lds_read128<s16_a_off<MODE, 0, 1>()>(a_addr);
+    f.x[0][2] = lds_read128<s16_a_off<MODE, 0, 2>()>(a_addr);
+    f.x[0][3] = lds_read128<s16_a_off<MODE, 0, 3>()>(a_addr);
+    f.w[0][0] = lds_read128<S::w_off(0, 0)>(b_addr);
+    f.w[0][1] = lds_read128<S::w_off(0, 1)>(b_addr);
+    f.w[1][0] = lds_read128<S::w_off(1, 0)>(b_addr);
+    f.w[1][1] = lds_read128<S::w_off(1, 1)>(b_addr);
+    wait_wx16<2>(f.w[0][0], f.w[0][1], f.x[0][0], f.x[0][1], f.x[0][2], f.x[0][3]);
+    s16_groups<TT, NT, MODE, 0, S::G0>(acc, f, a_addr, b_addr);
 }
-// the three tap rows of one 32-channel chunk; advances the ring pointers
-template <class TT, int NT, int MODE, bool FIN, int B_SLOT>
-__device__ __forceinline__ void s16_chunk(f32x4 (&acc)[4][2 * NT], Frag16& f, uint32_t& a_cur, uint32_t& a_oth, uint32_t& b_cur,
-                                          const uint32_t b_end) {
-    uint32_t bn = b_cur + B_SLOT;
-    bn = bn >= b_end ? bn - 4 * B_SLOT : bn;
-    __builtin_amdgcn_s_barrier();
-    s16_substage<TT, NT, MODE, 0, false>(acc, f, a_cur, b_cur, a_cur, bn);
-    b_cur = bn; bn = b_cur + B_SLOT; bn = bn >= b_end ? bn - 4 * B_SLOT : bn;
-    __builtin_amdgcn_s_barrier();
-    s16_substage<TT, NT, MODE, 1, false>(acc, f, a_cur, b_cur, a_cur, bn);
-    b_cur = bn; bn = b_cur + B_SLOT; bn = bn >= b_end ? bn - 4 * B_SLOT : bn;
-    __builtin_amdgcn_s_barrier();
-    s16_substage<TT, NT, MODE, 2, FIN>(acc, f, a_cur, b_cur, a_oth, bn);
-    b_cur = bn;
-    const uint32_t tmp = a_cur; a_cur = a_oth; a_oth = tmp;
-}
-template <int NT, int MODE> __device__ __forceinline__ void s16_prime(Frag16& f, uint32_t a_addr, uint32_t b_addr) {
-    s16_first_read<NT, MODE, 0, 0>(f, a_addr, b_addr);
-    s16_first_read<NT, MODE, 0, 1>(f, a_addr, b_addr);
-    s16_first_read<NT, MODE, 0, 2>(f, a_addr, b_addr);
-    s16_first_read<NT, MODE, 0, 3>(f, a_addr, b_addr);
-    s16_first_read<NT, MODE, 0, 4>(f, a_addr, b_addr);
-    s16_first_read<NT, MODE, 0, 5>(f, a_addr, b_addr);
-    s16_first_read<NT, MODE, 0, 6>(f, a_addr, b_addr);
-    s16_first_read<NT, MODE, 0, 7>(f, a_addr, b_addr);
+// second half: only the weights are new; pixel fragments requested before the barrier are simply older in the queue
+template <class TT, int NT, int MODE>
+__device__ __forceinline__ void s16_back(f32x4 (&acc)[4][2 * NT], Frag16& f, uint32_t a_addr, uint32_t b_addr) {
+    using S = S16Geo<NT>;
+    constexpr int G0 = S::G0, w0 = G0 % 3, w1 = (G0 + 1) % 3, xn = (G0 / NT) & 1;
+    f.w[w0][0] = lds_read128<S::w_off(G0, 0)>(b_addr);
+    f.w[w0][1] = lds_read128<S::w_off(G0, 1)>(b_addr);
+    f.w[w1][0] = lds_read128<S::w_off(G0 + 1, 0)>(b_addr);
+    f.w[w1][1] = lds_read128<S::w_off(G0 + 1, 1)>(b_addr);
+    wait_wx16<2>(f.w[w0][0], f.w[w0][1], f.x[xn][0], f.x[xn][1], f.x[xn][2], f.x[xn][3]);
+    s16_groups<TT, NT, MODE, G0, S::NG>(acc, f, a_addr, b_addr);
 }
 
 // accumulators -> plane-major tensor.  Lane (g, c) holds channels 4g..4g+3 of pixel c of each 16-channel fragment;
@@ -1399,11 +1372,13 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
     constexpr int A_PLANE = G::PLANE;
     constexpr int A_SLOT = 4 * A_PLANE;
     constexpr int A_INSTR = 4 * G::PLANE_ENT / 64;
-    constexpr int B_PIECES = 3 * NF;
-    constexpr int B_SLOT = B_PIECES * 1024;
-    constexpr int B_BASE = 2 * A_SLOT;  // LDS: [halo 0][halo 1][weights 0..3]
-    static_assert(3 * B_PIECES < 64 && A_INSTR < 64, "vmcnt is a 6-bit counter");
+    using SG = S16Geo<NT>;
+    constexpr int P0 = 2 * SG::G0, P1 = 2 * (SG::NG - SG::G0);  // DMA pieces of the two weight halves of a chunk
+    constexpr int B_SLOT = SG::B_SLOT;
+    constexpr int B_BASE = 2 * A_SLOT;  // LDS: [halo 0][halo 1][weights: first half][weights: second half]
+    static_assert(P0 < 64 && A_INSTR < 64, "vmcnt is a 6-bit counter");
     static_assert((4 * G::PLANE_ENT) % 64 == 0, "halo image = whole DMA instructions");
+    static_assert(2 * B_SLOT < 65536, "ds offset is 16 bits");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -1438,43 +1413,40 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
             int mt_, nt_;
             for (int i = cur; i < cnt; i = seek(i + step, mt_, nt_)) ++ntl;
         }
-        const int total = ntl * nchunks * 3;  // sub-stages = barriers
+        const int total = ntl * nchunks * 2;  // half-chunks = barriers
         int l_pos = cur;
         bool l_ok = true;
         if (w == 9) {
-            // ---- weight loader: a linear stream of 3 * nchunks sub-stages per tile through a 4-slot ring, three
-            //      sub-stages ahead; at barrier u it guarantees sub-stage u + 1 (whose first fragments the compute
-            //      waves request before barrier u + 1) ----
-            const int nsub = 3 * nchunks;
-            const char* wsrc = (const char*)a.wpk16 + (size_t)ntile * nsub * B_SLOT + lane * 16;
-            int l_u = 0, l_slot = 0, issued = 0;
+            // ---- weight loader: the two halves of each chunk, one half ahead (two slots: half u + 1 goes where half
+            //      u - 1 was, once everyone has passed barrier u) ----
+            const size_t chunk_bytes = (size_t)(P0 + P1) * 1024;
+            const char* wsrc = (const char*)a.wpk16 + (size_t)ntile * nchunks * chunk_bytes + lane * 16;
+            int l_kc = 0, l_half = 0;
             auto issue = [&]() __attribute__((always_inline)) {
                 if (!l_ok) return;
-                const char* src = wsrc + (size_t)l_u * B_SLOT;
-                char* dst = smem + B_BASE + l_slot * B_SLOT;
+                const char* src = wsrc + (size_t)l_kc * chunk_bytes;
+                if (l_half == 0) {
 #pragma unroll
-                for (int j = 0; j < B_PIECES; ++j) glds16(src + j * 1024, dst + j * 1024);
-                ++issued;
-                l_slot = (l_slot + 1) & 3;
-                if (++l_u == nsub) {
-                    l_u = 0;
-                    int mt_, nt_ = 0;
-                    l_pos = seek(l_pos + step, mt_, nt_);
-                    l_ok = l_pos < cnt;
-                    wsrc = (const char*)a.wpk16 + (size_t)nt_ * nsub * B_SLOT + lane * 16;
+                    for (int j = 0; j < P0; ++j) glds16(src + j * 1024, smem + B_BASE + j * 1024);
+                    l_half = 1;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < P1; ++j) glds16(src + (P0 + j) * 1024, smem + B_BASE + B_SLOT + j * 1024);
+                    l_half = 0;
+                    if (++l_kc == nchunks) {
+                        l_kc = 0;
+                        int mt_, nt_ = 0;
+                        l_pos = seek(l_pos + step, mt_, nt_);
+                        l_ok = l_pos < cnt;
+                        wsrc = (const char*)a.wpk16 + (size_t)nt_ * nchunks * chunk_bytes + lane * 16;
+                    }
                 }
             };
             issue();
-            issue();
-            issue();
-            // start-up barrier: sub-stage 0 has landed
-            if (issued >= 3) wait_vmcnt<2 * B_PIECES>(); else if (issued == 2) wait_vmcnt<B_PIECES>(); else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
             for (int u = 0; u < total; ++u) {
-                // sub-stage u + 1 has landed once only the sub-stages issued after it are outstanding
-                if (issued >= u + 3) wait_vmcnt<B_PIECES>(); else wait_vmcnt<0>();
+                wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();
-                issue();  // sub-stage u + 3 -> the slot of u - 1
+                issue();
             }
         } else {
             // ---- halo loader: one 4-plane image per 32-channel chunk, one chunk ahead ----
@@ -1522,14 +1494,10 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
                 }
             };
             issue();
-            wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();  // start-up barrier: chunk 0 has landed
-            int dy = 0;
             for (int u = 0; u < total; ++u) {
-                if (dy == 2) wait_vmcnt<0>();  // the next chunk is complete one barrier before its first sub-stage
+                if ((u & 1) == 0) wait_vmcnt<0>();  // a chunk's first barrier publishes its halo image
                 __builtin_amdgcn_s_barrier();
-                if (dy == 0) issue();          // chunk c + 1 -> the slot chunk c - 1 was read from
-                dy = dy == 2 ? 0 : dy + 1;
+                if ((u & 1) == 0) issue();          // chunk c + 1 -> the slot chunk c - 1 was read from
             }
         }
         return;
@@ -1541,11 +1509,7 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
     const uint32_t a_lane = lds_base + g * A_PLANE + ((G::ROW_PER_WAVE * w) * G::ROWW + c) * 16;
     const uint32_t b_lane = lds_base + B_BASE + lane * 16;
     uint32_t a_cur = a_lane, a_oth = a_lane + A_SLOT;  // this lane's address in the current / the other halo image
-    uint32_t b_cur = b_lane;                           // ... and in the current weight slot
-    const uint32_t b_end = b_lane + 4 * B_SLOT;
     Frag16 f;
-    __builtin_amdgcn_s_barrier();  // start-up barrier: chunk 0 and weight sub-stage 0 have landed
-    s16_prime<NT, MODE>(f, a_lane, b_lane);
     while (cur < cnt) {
         int b, y0, x0;
         tile_origin(mtile, b, y0, x0);
@@ -1554,13 +1518,17 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
         for (int pf = 0; pf < 4; ++pf)
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) acc[pf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int kc = 0; kc + 1 < nchunks; ++kc) s16_chunk<TT, NT, MODE, false, B_SLOT>(acc, f, a_cur, a_oth, b_cur, b_end);
-        s16_chunk<TT, NT, MODE, true, B_SLOT>(acc, f, a_cur, a_oth, b_cur, b_end);
+        for (int kc = 0; kc < nchunks; ++kc) {
+            __builtin_amdgcn_s_barrier();
+            s16_front<TT, NT, MODE>(acc, f, a_cur, b_lane);
+            __builtin_amdgcn_s_barrier();
+            s16_back<TT, NT, MODE>(acc, f, a_cur, b_lane);
+            const uint32_t tmp = a_cur; a_cur = a_oth; a_oth = tmp;
+        }
         const int nbase = ntile * BN;
         if (a.epi == EPI_D2S) store_epilogue16<TT, NT, MODE, EPI_D2S, false>(a, acc, lane, w, nbase, b, y0, x0);
         else if (a.silu) store_epilogue16<TT, NT, MODE, EPI_STORE, true>(a, acc, lane, w, nbase, b, y0, x0);
         else store_epilogue16<TT, NT, MODE, EPI_STORE, false>(a, acc, lane, w, nbase, b, y0, x0);
-        s16_prime<NT, MODE>(f, a_cur, b_cur);  // the next tile's first fragments (guaranteed since the last barrier)
         cur = seek(cur + step, mtile, ntile);
     }
 }
@@ -1741,10 +1709,10 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
     }
 }
 
-// the 16x16x32 kernel: two 4-plane halo images + four tap-row weight slots
+// the 16x16x32 kernel: two 4-plane halo images + the two halves of a chunk's weights
 size_t conv16_lds_bytes(int mode, int nt) {
     const size_t a_slot = 4 * (size_t)(mode == MODE_C3W16 ? 640 : 672) * 16;
-    return 2 * a_slot + 4 * (size_t)(3 * 2 * nt * 1024);
+    return 2 * a_slot + 2 * (size_t)(2 * ((9 * nt + 1) / 2) * 1024);
 }
 
 size_t conv_lds_bytes(int mode, int nt) {
