@@ -212,6 +212,37 @@ def run_validation_cases(ref):
     print("validation:", {k: v["raises"] for k, v in result.items()})
 
 
+def run_checkpoint_case(ref):
+    """g10: a TRAINING-style checkpoint of a tiny model as the reference itself writes it -- weight-norm
+    parametrised (model.py:117-122), then LoRA adapters (model.py:124-129, 1361-1390) with non-zero B factors, keys
+    prefixed like a torch.compile'd module -- and the plain weights `remove_parameterizations()` (model.py:131-139)
+    bakes from it.  Pins `bake_state_dict`."""
+    config = cfg(2, (8, 16, 16, 16), (2, 2, 2, 2))
+    alpha, rank = 0.75, 2
+    model = ref.MewZoom(**config)
+    sd0 = synth_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 21)
+    model.load_state_dict(sd0)
+    model.add_weight_norms()
+    model.add_lora_adapters(rank, alpha)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            if k.endswith("lora_b"):
+                v.copy_(torch.randn(v.shape, generator=g) * 0.05)
+            if k.endswith("original0"):
+                v.mul_(1.0 + 0.1 * torch.rand(v.shape, generator=g))  # g no longer equals |v|
+    raw = {"_orig_mod." + k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.remove_parameterizations()
+    baked = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    out = {"lora_alpha": np.float32(alpha), "lora_rank": np.int32(rank), "config_json": np.array(json.dumps(config))}
+    for k, v in raw.items():
+        out["raw/" + k] = v.numpy()
+    for k, v in baked.items():
+        out["baked/" + k] = v.numpy()
+    np.savez_compressed(HERE / "g10_checkpoint.npz", **out)
+    print("g10_checkpoint", len(raw), "raw keys ->", len(baked), "baked keys")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -225,6 +256,8 @@ def main():
         run_op_cases(ref)
     if not only or "validation" in only:
         run_validation_cases(ref)
+    if not only or "checkpoint" in only:
+        run_checkpoint_case(ref)
 
 
 if __name__ == "__main__":

@@ -72,3 +72,31 @@ def test_bake_weight_norm_checkpoint():
         assert torch.allclose(baked[k], sd[k], atol=1e-6), k
     m = MewZoom(**case.config)
     m.load_training_checkpoint(raw)
+
+
+def test_bake_reference_checkpoint_weight_norm_and_lora():
+    """g10: a checkpoint written by the reference itself (weight norm + LoRA adapters, `_orig_mod.` prefixes) and the
+    weights its own `remove_parameterizations()` produced from it."""
+    import json
+    from pathlib import Path
+
+    import numpy as np
+
+    d = np.load(Path(__file__).parent / "golden" / "g10_checkpoint.npz")
+    raw = {k[len("raw/"):]: torch.from_numpy(d[k]) for k in d.files if k.startswith("raw/")}
+    want = {k[len("baked/"):]: torch.from_numpy(d[k]) for k in d.files if k.startswith("baked/")}
+    alpha = float(d["lora_alpha"])
+    with pytest.raises(ValueError, match="lora_alpha"):
+        bake_state_dict(raw)
+    baked = bake_state_dict(raw, lora_alpha=alpha)
+    assert list(baked) and set(baked) == set(want)
+    for k, v in want.items():
+        assert baked[k].shape == v.shape, k
+        assert torch.allclose(baked[k], v, atol=2e-7, rtol=1e-6), (k, (baked[k] - v).abs().max().item())
+    m = MewZoom(**json.loads(str(d["config_json"])))
+    m.load_training_checkpoint(raw, lora_alpha=alpha)
+    for k, v in m.state_dict().items():
+        assert torch.allclose(v, want[k], atol=2e-7, rtol=1e-6), k
+    # a wrong alpha must not pass silently
+    off = bake_state_dict(raw, lora_alpha=alpha * 2)
+    assert any((off[k] - want[k]).abs().max().item() > 1e-3 for k in want if k.endswith("conv.weight"))

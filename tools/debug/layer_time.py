@@ -13,6 +13,6 @@ x = (torch.rand(B, cin // 8, H, W, 8, device="cuda") * 2 - 1).to(dtype)
 w = ((torch.rand(cout, cin, 3, 3, device="cuda") * 2 - 1) * (3.0 / (9 * cin)) ** 0.5 * 1.7).float().contiguous()
 out = alloc_act(B, cout, H, W, dtype)
 for _ in range(n):
-    op_conv(dtype, 0, x, None, w, 0.0, out, B, H, W, cin, cout, silu=1)
+    op_conv(dtype, 0, x, None, w, 0.0, out, B, H, W, cin, cout, silu=int(os.environ.get("MZ_LAYER_SILU", "1")))
 torch.cuda.synchronize()
 print("done", out.float().abs().mean().item())

@@ -652,7 +652,9 @@ struct Runner {
         pick_order(a, c, px * c.cp0 * sz);
         if (mode != MODE_CONV3 && (epi == EPI_STORE || epi == EPI_D2S) && persist_wgs > 0) {
             // 16-bit types: the 16x16x32-MFMA kernel (persistent only; 32-bit halo offsets span four planes)
-            if (c.packed16 && use_s16 && (double)H * W * 64.0 < 4294967296.0) {
+            // ... and only where padding K to whole 32-channel chunks wastes less than the shape gains (~12 %)
+            const bool k_fits = c.nchunks16 * 32 * 8 <= c.cp0 * 9;
+            if (c.packed16 && use_s16 && k_fits && (double)H * W * 64.0 < 4294967296.0) {
                 a.s16 = 1; a.wpk16 = c.packed16; a.nchunks16 = c.nchunks16;
                 const int need = (a.grid + 7) / 8 * 8;
                 a.persist = need < persist_wgs ? need : persist_wgs;

@@ -256,31 +256,53 @@ class MewZoom(nn.Module, PyTorchModelHubMixin):
         return engine.run_u8(x.contiguous(), self.max_images_in_flight)
 
     # ---- checkpoint ingestion (test_compare.py:32-45 of the reference) -------------------------
-    def load_training_checkpoint(self, state_dict: Dict[str, Tensor]) -> None:
-        """Loads a raw training checkpoint: strips ``_orig_mod.`` prefixes left by torch.compile and
-        bakes weight-norm parametrisations (w = g * v / ||v||, norm over all dims but 0) into plain
-        ``conv.weight`` tensors, which is what the reference does with ``add_weight_norms`` ->
-        ``load_state_dict`` -> ``remove_parameterizations``."""
-        self.load_state_dict(bake_state_dict(state_dict))
+    def load_training_checkpoint(self, state_dict: Dict[str, Tensor], lora_alpha: Optional[float] = None) -> None:
+        """Loads a raw training checkpoint: strips ``_orig_mod.`` prefixes left by torch.compile, bakes weight-norm
+        parametrisations (w = g * v / ||v||) and merges LoRA adapters (needs ``lora_alpha``) into plain
+        ``conv.weight`` tensors -- what the reference does with ``add_weight_norms`` / ``add_lora_adapters`` ->
+        ``load_state_dict`` -> ``remove_parameterizations`` (test_compare.py:32-45)."""
+        self.load_state_dict(bake_state_dict(state_dict, lora_alpha))
 
 
-def bake_state_dict(state_dict: Dict[str, Tensor]) -> Dict[str, Tensor]:
-    """Turns a training-time state_dict into the baked layout this model (and the HF export) uses."""
+def bake_state_dict(state_dict: Dict[str, Tensor], lora_alpha: Optional[float] = None) -> Dict[str, Tensor]:
+    """Turns a training-time state_dict into the baked layout this model (and the HF export) uses: what the
+    reference's `remove_parameterizations()` leaves behind (model.py:131-139, test_compare.py:32-45).
+
+    * `_orig_mod.` prefixes of torch.compile'd modules are stripped;
+    * weight norm (`add_weight_norms`, model.py:117-122): `w = g * v / ||v||`, norm over all dims but 0;
+    * LoRA adapters (`add_lora_adapters`, model.py:124-129; `ChannelLoRA.forward`, model.py:1361-1390):
+      `w += alpha * (A @ B).permute(2, 3, 0, 1)` with A `[kh, kw, out, rank]`, B `[kh, kw, rank, in]`.  `alpha` is a
+      Python attribute of the adapter, not a tensor, so it is not in the checkpoint: pass it as `lora_alpha`.
+    Parametrizations apply in registration order (weight norm can only be the first one)."""
     sd = {k.replace("_orig_mod.", ""): v for k, v in state_dict.items()}
+    marker = ".parametrizations.weight."
     out: Dict[str, Tensor] = {}
-    g_suffix = ".parametrizations.weight.original0"
-    v_suffix = ".parametrizations.weight.original1"
+    groups: Dict[str, Dict[str, Tensor]] = {}
     for k, v in sd.items():
-        if k.endswith(g_suffix):
-            base = k[: -len(g_suffix)]
-            g = v
-            vv = sd[base + v_suffix]
-            norm = vv.flatten(1).norm(dim=1).reshape(-1, *([1] * (vv.dim() - 1)))
-            out[base + ".weight"] = g * vv / norm
-        elif k.endswith(v_suffix):
-            continue
+        if marker in k:
+            base, leaf = k.split(marker, 1)
+            groups.setdefault(base, {})[leaf] = v
         else:
             out[k] = v
+    for base, leaves in groups.items():
+        if "original" in leaves:
+            w = leaves["original"].clone()
+        elif "original0" in leaves and "original1" in leaves:
+            g, vv = leaves["original0"], leaves["original1"]
+            norm = vv.flatten(1).norm(dim=1).reshape(-1, *([1] * (vv.dim() - 1)))
+            w = g * vv / norm
+        else:
+            raise KeyError(f"{base}: parametrized weight without its original tensor(s): {sorted(leaves)}")
+        adapters = sorted({int(leaf.split(".")[0]) for leaf in leaves if leaf.endswith((".lora_a", ".lora_b"))})
+        unknown = [leaf for leaf in leaves if not leaf.startswith("original") and not leaf.endswith((".lora_a", ".lora_b"))]
+        if unknown:
+            raise KeyError(f"{base}: unknown parametrization tensors {unknown}")
+        for i in adapters:
+            if lora_alpha is None:
+                raise ValueError("the checkpoint holds LoRA adapters: pass lora_alpha (the `alpha` given to add_lora_adapters)")
+            a, b = leaves[f"{i}.lora_a"], leaves[f"{i}.lora_b"]
+            w = w + float(lora_alpha) * (a.to(w.dtype) @ b.to(w.dtype)).permute(2, 3, 0, 1)
+        out[base + ".weight"] = w
     return out
 
 
