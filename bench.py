@@ -83,10 +83,10 @@ def host_cores() -> int:
 
 
 def traffic_from_profile(args, per_gpu):
-    """HBM-side bytes per 3x3-kernel launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic_conv3w.json:
+    """HBM-side bytes per 3x3-kernel launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic_conv3x3.json:
     FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate passes, same command with a 3-image micro-batch).
     PMC counters cannot be collected from inside this process, so the figure is only quoted for the profiled workload."""
-    path = REPO / "profiles" / "r01_pmc_traffic_conv3w.json"
+    path = REPO / "profiles" / "r01_pmc_traffic_conv3x3.json"
     if args.workload != "cfg3_1080p" or args.dtype != "bf16" or not path.exists():
         return None
     try:
@@ -246,7 +246,7 @@ def main():
             "whole_path_tflops_per_gpu": flops_step * args.steps / elapsed / 1e12,
             "roofline": {
                 "bound": "mfma",
-                "kernel": "conv_kernel<3x3 implicit GEMM> (all launches of one step, rank 0)",
+                "kernel": "3x3 implicit-GEMM convolution kernels conv3s_kernel / conv3w_kernel (all launches of one step, rank 0)",
                 "achieved": conv_tflops,
                 "peak": peak,
                 "unit": "TFLOP/s",

@@ -9,9 +9,11 @@ for f in glob.glob(os.path.join(root, "*", "*", "*_counter_collection.csv")):
     seen = set()
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        if "conv_kernel" not in name and "conv3w_kernel" not in name: continue
-        short = ("W:" if "conv3w" in name else "") + name.split("_kernel<")[1].split(">")[0].replace("mz::", "")
-        key = (short, int(r["Grid_Size"]) // 256)
+        tags = {"conv3s_kernel": "S16:", "conv3p_kernel": "P:", "conv3w_kernel": "W:", "conv_kernel": ""}
+        tag = next((t for k, t in tags.items() if k in name), None)
+        if tag is None: continue
+        short = tag + name.split("_kernel<")[1].split(">")[0].replace("mz::", "")
+        key = (short, int(r["Grid_Size"]) // int(r.get("Workgroup_Size", 256) or 256))
         data[key][r["Counter_Name"]] += float(r["Counter_Value"])
         did = (f, r["Dispatch_Id"])
         if did not in seen:
