@@ -38,7 +38,7 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
 from ultrazoom_amd import MewZoom  # noqa: E402
-from ultrazoom_amd.sharding import gather_outputs  # noqa: E402
+from ultrazoom_amd.sharding import upscale_local_overlapped  # noqa: E402
 from ultrazoom_amd.synth import synth_image, synth_state_dict  # noqa: E402
 
 MODELS = {
@@ -180,11 +180,16 @@ def main():
     global_batch = per_gpu * world
     do_gather = world > 1 and not args.no_gather
 
+    # N > 1: the gather of a chunk's outputs travels while the next chunk is computed (only the last chunk's transfer
+    # is exposed); the chunk equals the library's micro-batch so that no image runs alone
+    chunk = args.images_in_flight if args.images_in_flight > 0 else 4
+    if do_gather:
+        model.max_images_in_flight = chunk
+
     def step():
-        y = model.upscale(x)
         if do_gather:
-            return gather_outputs(y, global_batch, dst=0)
-        return y
+            return upscale_local_overlapped(model, x, dst=0, chunk=chunk)
+        return model.upscale(x)
 
     def sync():
         if world > 1:

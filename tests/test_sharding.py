@@ -51,6 +51,12 @@ def _worker(rank, world, port, batch, result_path):
             torch.save({"ok": bool(torch.equal(out, want)), "shape": tuple(out.shape)}, result_path)
         else:
             assert out is None
+        # the overlapped variant (chunked asynchronous gathers into views of the final tensor) gives the same tensor
+        out2 = upscale_sharded(_FakeModel(), x, dst=0, overlap_chunk=1)
+        if rank == 0:
+            assert torch.equal(out2, _FakeModel().upscale(x))
+        else:
+            assert out2 is None
         lo, hi = shard_range(batch, world, rank)
         full = gather_outputs(torch.full((hi - lo, 2), float(rank)), batch, dst=1)
         if rank == 1:
@@ -67,3 +73,30 @@ def test_upscale_sharded_world2_gloo(tmp_path, batch):
     mp.spawn(_worker, args=(2, _free_port(), batch, str(path)), nprocs=2, join=True)
     res = torch.load(path)
     assert res["ok"] and res["shape"] == (batch, 3, 10, 14)
+
+
+def _worker_overlap(rank, world, port, result_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ultrazoom_amd.sharding import upscale_local_overlapped
+
+        per = 5  # chunks of 2, 2, 1
+        x_local = torch.rand(per, 3, 4, 6, generator=torch.Generator().manual_seed(10 + rank))
+        out = upscale_local_overlapped(_FakeModel(), x_local, dst=1, chunk=2)
+        if rank == 1:
+            want = torch.cat([_FakeModel().upscale(torch.rand(per, 3, 4, 6, generator=torch.Generator().manual_seed(10 + r)))
+                              for r in range(world)])
+            torch.save({"ok": bool(torch.equal(out, want)), "shape": tuple(out.shape)}, result_path)
+        else:
+            assert out is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_gather_world2_gloo(tmp_path):
+    path = tmp_path / "result.pt"
+    mp.spawn(_worker_overlap, args=(2, _free_port(), str(path)), nprocs=2, join=True)
+    res = torch.load(path)
+    assert res["ok"] and res["shape"] == (10, 3, 8, 12)

@@ -61,13 +61,49 @@ def gather_outputs(local: Tensor, batch: int, dst: int = 0, group=None) -> Optio
     return None
 
 
-def upscale_sharded(model, x: Tensor, dst: int = 0, group=None, gather: bool = True) -> Optional[Tensor]:
+def upscale_sharded(model, x: Tensor, dst: int = 0, group=None, gather: bool = True, overlap_chunk: int = 0) -> Optional[Tensor]:
     """`x` is the FULL batch (same on every rank, or at least this rank's slice must be valid): each rank
-    upscales its contiguous slice; with `gather` the outputs are collected on `dst`."""
+    upscales its contiguous slice; with `gather` the outputs are collected on `dst`.
+    `overlap_chunk` > 0: see `upscale_local_overlapped` (equal slices only; otherwise the plain path is taken)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     lo, hi = shard_range(x.shape[0], world, rank)
+    if gather and overlap_chunk > 0 and len(set(shard_sizes(x.shape[0], world))) == 1:
+        return upscale_local_overlapped(model, x[lo:hi], dst=dst, group=group, chunk=overlap_chunk)
     local = model.upscale(x[lo:hi])
     if not gather:
         return local
     return gather_outputs(local, x.shape[0], dst=dst, group=group)
+
+
+def upscale_local_overlapped(model, x_local: Tensor, dst: int = 0, group=None, chunk: int = 4) -> Optional[Tensor]:
+    """Upscale + gather with the exchange hidden under the compute: this rank's slice (EVERY rank must hold the same
+    number of images) is upscaled `chunk` images at a time, and each chunk's outputs start travelling to `dst` as an
+    asynchronous gather while the next chunk is being computed -- only the last chunk's transfer is exposed.  The
+    receive buffers are views of the final [world * n, ...] tensor, so nothing is copied twice.  With RCCL the
+    collectives run on the backend's own stream, ordered after the producing kernels; `wait()` orders the caller's
+    stream after them without blocking the host."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n = x_local.shape[0]
+    chunk = max(1, int(chunk))
+    via_host = x_local.is_cuda and dist.get_backend(group) == "gloo"  # rehearsals: gloo moves host memory only
+    full = None
+    works, keep = [], []
+    for c0 in range(0, n, chunk):
+        c1 = min(n, c0 + chunk)
+        y = model.upscale(x_local[c0:c1]).contiguous()
+        wire = y.cpu() if via_host else y
+        bufs = None
+        if rank == dst:
+            if full is None:
+                full = torch.empty((world * n,) + tuple(wire.shape[1:]), dtype=wire.dtype, device=wire.device)
+            bufs = [full[i * n + c0 : i * n + c1] for i in range(world)]
+        works.append(dist.gather(wire, gather_list=bufs, dst=dst, group=group, async_op=True))
+        keep.append(wire)  # the send buffer must outlive the transfer
+    for w in works:
+        w.wait()
+    keep.clear()
+    if full is None:
+        return None
+    return full.to(x_local.device) if via_host else full
