@@ -66,6 +66,9 @@ PERSIST_CASES = [
     (1, 40, 200, 48, 192, 0),   # 8x64 tiles, two N tiles (weights change at tile boundaries)
     (3, 33, 65, 16, 288, 1),    # one K-stage per tile: every barrier is a tile boundary
     (1, 70, 70, 96, 40, 0),     # padded N, 6 K-stages
+    (2, 33, 65, 64, 96, 1),     # 16x32 tiles on the 16x16x32 kernel (16-bit types), ragged in both directions
+    (1, 20, 130, 144, 96, 0),   # Cin = 144: the last 32-channel chunk of the 16x16x32 kernel is half zero planes
+    (1, 24, 200, 160, 192, 1),  # 5 chunks, two N tiles, right-edge tiles with pixel fragments outside the image
 ]
 
 
