@@ -1369,6 +1369,19 @@ __device__ __forceinline__ void store_epilogue16(const ConvArgs& a, f32x4 (&acc)
     }
 }
 
+// -DMZ_STAMP=2 diagnostic build: where the waves of one workgroup spend each half-chunk (tools/stamp_probe16.py)
+#if defined(MZ_STAMP) && MZ_STAMP >= 2
+#define S16STAMP(u, k)                                                                                            \
+    do {                                                                                                          \
+        if (a.dbg && blockIdx.x == gridDim.x / 2 && (u) < 64 && lane == 0) {                                       \
+            unsigned long long t_;                                                                                \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                            \
+            a.dbg[((w * 64) + (u)) * 8 + (k)] = t_;                                                               \
+        }                                                                                                         \
+    } while (0)
+#else
+#define S16STAMP(u, k) do { } while (0)
+#endif
 template <class TT, int NT, int MODE>
 __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
     using G = Geo<MODE>;
@@ -1449,9 +1462,13 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
             };
             issue();
             for (int u = 0; u < total; ++u) {
+                S16STAMP(u, 0);
                 wait_vmcnt<0>();
+                S16STAMP(u, 1);
                 __builtin_amdgcn_s_barrier();
+                S16STAMP(u, 2);
                 issue();
+                S16STAMP(u, 3);
             }
         } else {
             // ---- halo loader: one 4-plane image per 32-channel chunk, one chunk ahead ----
@@ -1500,9 +1517,13 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
             };
             issue();
             for (int u = 0; u < total; ++u) {
+                S16STAMP(u, 0);
                 if ((u & 1) == 0) wait_vmcnt<0>();  // a chunk's first barrier publishes its halo image
+                S16STAMP(u, 1);
                 __builtin_amdgcn_s_barrier();
+                S16STAMP(u, 2);
                 if ((u & 1) == 0) issue();          // chunk c + 1 -> the slot chunk c - 1 was read from
+                S16STAMP(u, 3);
             }
         }
         return;
@@ -1515,6 +1536,9 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
     const uint32_t b_lane = lds_base + B_BASE + lane * 16;
     uint32_t a_cur = a_lane, a_oth = a_lane + A_SLOT;  // this lane's address in the current / the other halo image
     Frag16 f;
+#if defined(MZ_STAMP) && MZ_STAMP >= 2
+    int ustamp = 0;  // chunks done by this workgroup
+#endif
     while (cur < cnt) {
         int b, y0, x0;
         tile_origin(mtile, b, y0, x0);
@@ -1533,10 +1557,18 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
         }
         live = __builtin_amdgcn_readfirstlane(live);
         for (int kc = 0; kc < nchunks; ++kc) {
+            S16STAMP(ustamp, 0);
             __builtin_amdgcn_s_barrier();
+            S16STAMP(ustamp, 1);
             s16_front<TT, NT, MODE>(acc, f, a_cur, b_lane, live);
+            S16STAMP(ustamp, 2);
             __builtin_amdgcn_s_barrier();
+            S16STAMP(ustamp, 3);
             s16_back<TT, NT, MODE>(acc, f, a_cur, b_lane, live);
+            S16STAMP(ustamp, 4);
+#if defined(MZ_STAMP) && MZ_STAMP >= 2
+            ++ustamp;
+#endif
             const uint32_t tmp = a_cur; a_cur = a_oth; a_oth = tmp;
         }
         const int nbase = ntile * BN;
