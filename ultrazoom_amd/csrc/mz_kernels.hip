@@ -1242,6 +1242,7 @@ template <int NT> struct S16Geo {
 template <int NT, int G, int GE> struct S16Plan {  // group G of the segment ending at GE
     static constexpr int t = G / NT, n = G % NT;
     static constexpr bool w_issue = G + 2 < GE;
+    // (requesting all four in the tap's first group keeps them live a group longer: 30 spilled VGPRs, +12 % time)
     static constexpr int x_count = t + 1 < 9 ? (NT == 3 ? (n < 2 ? 2 : 0) : (n == 0 ? 4 : 0)) : 0;
     static constexpr int x_first = NT == 3 ? 2 * n : 0;
     static constexpr int issued = (w_issue ? 2 : 0) + x_count;  // reads requested during this group
@@ -1560,10 +1561,16 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
             S16STAMP(ustamp, 0);
             __builtin_amdgcn_s_barrier();
             S16STAMP(ustamp, 1);
+#if MZ_ABLATE & 512  // timing-only: the younger wave of every SIMD does no matrix work (what does ONE wave per SIMD sustain?)
+            if (w < 4)
+#endif
             s16_front<TT, NT, MODE>(acc, f, a_cur, b_lane, live);
             S16STAMP(ustamp, 2);
             __builtin_amdgcn_s_barrier();
             S16STAMP(ustamp, 3);
+#if MZ_ABLATE & 512
+            if (w < 4)
+#endif
             s16_back<TT, NT, MODE>(acc, f, a_cur, b_lane, live);
             S16STAMP(ustamp, 4);
 #if defined(MZ_STAMP) && MZ_STAMP >= 2
