@@ -12,7 +12,7 @@ from ultrazoom_amd.synth import synth_image, synth_state_dict
 
 GOLDEN = Path(__file__).resolve().parent / "golden"
 
-MODEL_CASES = sorted(p.stem for p in GOLDEN.glob("g*.npz") if p.stem != "g6_ops")
+MODEL_CASES = sorted(p.stem for p in GOLDEN.glob("g*.npz") if p.stem not in ("g6_ops", "g10_checkpoint"))
 
 
 class GoldenCase:
