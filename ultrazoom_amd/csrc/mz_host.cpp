@@ -656,7 +656,6 @@ struct Runner {
             const bool k_fits = c.nchunks16 * 32 * 8 <= c.cp0 * 9;
             if (c.packed16 && use_s16 && k_fits && (double)H * W * 64.0 < 4294967296.0) {
                 a.s16 = 1; a.wpk16 = c.packed16; a.nchunks16 = c.nchunks16;
-                a.no_frag_skip = getenv("MZ_NO_FRAG_SKIP") != nullptr;
                 const int need = (a.grid + 7) / 8 * 8;
                 a.persist = need < persist_wgs ? need : persist_wgs;
             } else if (a.grid > persist_wgs) {

@@ -68,7 +68,6 @@ struct ConvArgs {
     int s16;           // persistent launches of 16-bit types: use the 16x16x32-MFMA kernel (needs wpk16)
     const void* wpk16; // weights packed for it: [ntile][32-channel chunk][tap][2*nt][64 lanes][16 B]
     int nchunks16;     // 32-channel chunks
-    int no_frag_skip;  // A/B timing: also run the MFMAs of pixel fragments that lie wholly outside the image
     int use_glds;      // stage through global_load_lds (1) or through registers (0)
     unsigned long long* dbg;  // -DMZ_STAMP diagnostic builds: per-stage s_memtime stamps of one workgroup
 };

@@ -1251,17 +1251,12 @@ template <int NT, int G, int GE> struct S16Plan {  // group G of the segment end
     static constexpr int allow = NT == 1 ? (w_issue ? 2 : 0) : issued;
 };
 template <class TT, int NT, int MODE, int G, int GE, int M>
-__device__ __forceinline__ void s16_mfmas(f32x4 (&acc)[4][2 * NT], Frag16& f, uint32_t a_addr, uint32_t b_addr, const int live) {
+__device__ __forceinline__ void s16_mfmas(f32x4 (&acc)[4][2 * NT], Frag16& f, uint32_t a_addr, uint32_t b_addr) {
     if constexpr (M < 8) {
         using P = S16Plan<NT, G, GE>;
         constexpr int t = P::t, n = P::n, xp = t & 1, wp = G % 3;
         constexpr int k = M >> 2, pf = M & 3;
-        // pixel fragments 2 and 3 that lie wholly outside the image (ragged right / bottom edge) cost no MFMA
-        if constexpr (pf >= 2) {
-            if (live & (1 << pf)) mma16<TT>(acc[pf][2 * n + k], f.w[wp][k], f.x[xp][pf]);
-        } else {
-            mma16<TT>(acc[pf][2 * n + k], f.w[wp][k], f.x[xp][pf]);
-        }
+        mma16<TT>(acc[pf][2 * n + k], f.w[wp][k], f.x[xp][pf]);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (P::w_issue && M < 2) {
             f.w[(G + 2) % 3][M] = lds_read128<S16Geo<NT>::w_off(G + 2, M)>(b_addr);
@@ -1272,15 +1267,15 @@ __device__ __forceinline__ void s16_mfmas(f32x4 (&acc)[4][2 * NT], Frag16& f, ui
             f.x[xp ^ 1][pfn] = lds_read128<s16_a_off<MODE, t + 1, pfn>()>(a_addr);
             __builtin_amdgcn_sched_barrier(0);
         }
-        s16_mfmas<TT, NT, MODE, G, GE, M + 1>(acc, f, a_addr, b_addr, live);
+        s16_mfmas<TT, NT, MODE, G, GE, M + 1>(acc, f, a_addr, b_addr);
     }
 }
 template <class TT, int NT, int MODE, int G, int GE>
-__device__ __forceinline__ void s16_groups(f32x4 (&acc)[4][2 * NT], Frag16& f, uint32_t a_addr, uint32_t b_addr, const int live) {
+__device__ __forceinline__ void s16_groups(f32x4 (&acc)[4][2 * NT], Frag16& f, uint32_t a_addr, uint32_t b_addr) {
     if constexpr (G < GE) {
         using P = S16Plan<NT, G, GE>;
         __builtin_amdgcn_sched_barrier(0);
-        s16_mfmas<TT, NT, MODE, G, GE, 0>(acc, f, a_addr, b_addr, live);
+        s16_mfmas<TT, NT, MODE, G, GE, 0>(acc, f, a_addr, b_addr);
         if constexpr (G + 1 < GE) {
             constexpr int wn = (G + 1) % 3, xn = ((G + 1) / NT) & 1;
             if constexpr ((G + 1) % NT == 0)  // the next group starts a new tap: its pixel fragments must be in
@@ -1288,12 +1283,12 @@ __device__ __forceinline__ void s16_groups(f32x4 (&acc)[4][2 * NT], Frag16& f, u
             else
                 wait_w16<P::allow>(f.w[wn][0], f.w[wn][1]);
         }
-        s16_groups<TT, NT, MODE, G + 1, GE>(acc, f, a_addr, b_addr, live);
+        s16_groups<TT, NT, MODE, G + 1, GE>(acc, f, a_addr, b_addr);
     }
 }
 // first half of a chunk: a new halo image and the first weight half have just been published by the barrier
 template <class TT, int NT, int MODE>
-__device__ __forceinline__ void s16_front(f32x4 (&acc)[4][2 * NT], Frag16& f, uint32_t a_addr, uint32_t b_addr, const int live) {
+__device__ __forceinline__ void s16_front(f32x4 (&acc)[4][2 * NT], Frag16& f, uint32_t a_addr, uint32_t b_addr) {
     using S = S16Geo<NT>;
     f.x[0][0] = lds_read128<s16_a_off<MODE, 0, 0>()>(a_addr);
     f.x[0][1] = lds_read128<s16_a_off<MODE, 0, 1>()>(a_addr);
@@ -1304,11 +1299,11 @@ __device__ __forceinline__ void s16_front(f32x4 (&acc)[4][2 * NT], Frag16& f, ui
     f.w[1][0] = lds_read128<S::w_off(1, 0)>(b_addr);
     f.w[1][1] = lds_read128<S::w_off(1, 1)>(b_addr);
     wait_wx16<2>(f.w[0][0], f.w[0][1], f.x[0][0], f.x[0][1], f.x[0][2], f.x[0][3]);
-    s16_groups<TT, NT, MODE, 0, S::G0>(acc, f, a_addr, b_addr, live);
+    s16_groups<TT, NT, MODE, 0, S::G0>(acc, f, a_addr, b_addr);
 }
 // second half: only the weights are new; pixel fragments requested before the barrier are simply older in the queue
 template <class TT, int NT, int MODE>
-__device__ __forceinline__ void s16_back(f32x4 (&acc)[4][2 * NT], Frag16& f, uint32_t a_addr, uint32_t b_addr, const int live) {
+__device__ __forceinline__ void s16_back(f32x4 (&acc)[4][2 * NT], Frag16& f, uint32_t a_addr, uint32_t b_addr) {
     using S = S16Geo<NT>;
     constexpr int G0 = S::G0, w0 = G0 % 3, w1 = (G0 + 1) % 3, xn = (G0 / NT) & 1;
     f.w[w0][0] = lds_read128<S::w_off(G0, 0)>(b_addr);
@@ -1316,7 +1311,7 @@ __device__ __forceinline__ void s16_back(f32x4 (&acc)[4][2 * NT], Frag16& f, uin
     f.w[w1][0] = lds_read128<S::w_off(G0 + 1, 0)>(b_addr);
     f.w[w1][1] = lds_read128<S::w_off(G0 + 1, 1)>(b_addr);
     wait_wx16<2>(f.w[w0][0], f.w[w0][1], f.x[xn][0], f.x[xn][1], f.x[xn][2], f.x[xn][3]);
-    s16_groups<TT, NT, MODE, G0, S::NG>(acc, f, a_addr, b_addr, live);
+    s16_groups<TT, NT, MODE, G0, S::NG>(acc, f, a_addr, b_addr);
 }
 
 // accumulators -> plane-major tensor.  Lane (g, c) holds channels 4g..4g+3 of pixel c of each 16-channel fragment;
@@ -1548,15 +1543,6 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
         for (int pf = 0; pf < 4; ++pf)
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) acc[pf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // bit pf: pixel fragment pf of this wave has a pixel inside the image
-        int live = 0;
-#pragma unroll
-        for (int pf = 0; pf < 4; ++pf) {
-            const int py = G::ROW_PER_WAVE == 2 ? y0 + 2 * w + (pf >> 1) : y0 + w;
-            const int px = G::ROW_PER_WAVE == 2 ? x0 + 16 * (pf & 1) : x0 + 16 * pf;
-            if ((py < a.H && px < a.W) || a.no_frag_skip) live |= 1 << pf;
-        }
-        live = __builtin_amdgcn_readfirstlane(live);
         for (int kc = 0; kc < nchunks; ++kc) {
             S16STAMP(ustamp, 0);
             __builtin_amdgcn_s_barrier();
@@ -1564,14 +1550,14 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
 #if MZ_ABLATE & 512  // timing-only: the younger wave of every SIMD does no matrix work (what does ONE wave per SIMD sustain?)
             if (w < 4)
 #endif
-            s16_front<TT, NT, MODE>(acc, f, a_cur, b_lane, live);
+            s16_front<TT, NT, MODE>(acc, f, a_cur, b_lane);
             S16STAMP(ustamp, 2);
             __builtin_amdgcn_s_barrier();
             S16STAMP(ustamp, 3);
 #if MZ_ABLATE & 512
             if (w < 4)
 #endif
-            s16_back<TT, NT, MODE>(acc, f, a_cur, b_lane, live);
+            s16_back<TT, NT, MODE>(acc, f, a_cur, b_lane);
             S16STAMP(ustamp, 4);
 #if defined(MZ_STAMP) && MZ_STAMP >= 2
             ++ustamp;
