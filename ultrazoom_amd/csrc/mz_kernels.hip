@@ -1467,13 +1467,12 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
                 S16STAMP(u, 3);
             }
         } else {
-            // ---- halo loader: one 4-plane image per 32-channel chunk, one chunk ahead ----
+            // ---- halo loader: one 4-plane image per 32-channel chunk, one chunk ahead.  Buffer-addressed LDS-DMA: the
+            //      descriptor covers exactly the planes of this chunk that exist (2 or 4), so halo pixels outside the
+            //      image (offset 0xffffffff) and the missing planes of a half chunk read as zeros by the hardware's
+            //      range check -- no zero page, no per-lane 64-bit address arithmetic in the issue loop ----
             const long long plane_in = (long long)a.H * a.W * 16;
             uint32_t aoff[A_INSTR];
-            unsigned long long hi_planes = 0;  // bit j: instruction j's entry of this lane lies in plane 2 or 3
-#pragma unroll
-            for (int j = 0; j < A_INSTR; ++j)
-                if ((64 * j + lane) / G::PLANE_ENT >= 2) hi_planes |= 1ull << j;
             const char* img = nullptr;
             auto set_tile = [&](int mt) __attribute__((always_inline)) {
                 int b, y0, x0;
@@ -1494,14 +1493,14 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
             int l_kc = 0, l_slot = 0;
             auto issue = [&]() __attribute__((always_inline)) {
                 if (!l_ok) return;
-                const char* src = img + 4LL * l_kc * plane_in;
-                const bool half = 4 * l_kc + 2 >= a.p0;  // the tensor ends after this chunk's first two planes
+                const int planes = a.p0 - 4 * l_kc < 4 ? a.p0 - 4 * l_kc : 4;
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)(img + 4LL * l_kc * plane_in), 0, (int)(uint32_t)(planes * plane_in), 0x00020000);
                 char* dst = smem + l_slot * A_SLOT;
 #pragma unroll
-                for (int j = 0; j < A_INSTR; ++j) {
-                    const bool zero = aoff[j] == 0xffffffffu || (half && ((hi_planes >> j) & 1));
-                    glds16(zero ? (const char*)a.zero : src + aoff[j], dst + j * 1024);
-                }
+                for (int j = 0; j < A_INSTR; ++j)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + j * 1024), 16,
+                                                             (int)aoff[j], 0, 0, 0);
                 l_slot ^= 1;
                 if (++l_kc == nchunks) {
                     l_kc = 0;
