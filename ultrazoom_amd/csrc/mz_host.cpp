@@ -189,6 +189,10 @@ static void add_block(mz_handle* h, BlockW* b, const std::string& prefix, int c)
         const int zg = h->dtype == DT_F32 ? 4 : 2;
         f.nchunks = f.nchunks_real = f.cp0 / chunk_channels(h->dtype) + f.nt * zg;
         f.packed_sz = packed_bytes(1, f.nt, 1, f.nchunks);
+        if (h->dtype != DT_F32) {  // second packing for the fused epilogue of the 16x16x32 kernel: 2 nt K-steps x 2 nt fragments
+            f.nchunks16 = (f.cp0 + 31) / 32 + f.nt;
+            f.packed16_sz = packed_bytes(1, 2 * f.nt, 1, f.nchunks16);
+        }
     }
     add_slot(h, prefix + ".convnet.conv1.weight", SK_CONV, {hr * c, c, 3, 3});
     h->slots.back().conv = &b->conv1;
@@ -650,12 +654,15 @@ struct Runner {
         const double sz = dtype_size(dtype);
         const double px = (double)B * H * W;
         pick_order(a, c, px * c.cp0 * sz);
-        if (mode != MODE_CONV3 && (epi == EPI_STORE || epi == EPI_D2S) && persist_wgs > 0) {
+        const bool fuse16 = epi == EPI_FUSEDMIX && mixf && mixf->packed16 && !getenv("MZ_NO_FUSE16") &&
+                            (mixf->cp0 + 31) / 32 == c.nt;  // x K-steps == z K-steps (always so for C <= 96)
+        if (mode != MODE_CONV3 && (epi == EPI_STORE || epi == EPI_D2S || fuse16) && persist_wgs > 0) {
             // 16-bit types: the 16x16x32-MFMA kernel (persistent only; 32-bit halo offsets span four planes)
             // ... and only where padding K to whole 32-channel chunks wastes less than the shape gains (~12 %)
             const bool k_fits = c.nchunks16 * 32 * 8 <= c.cp0 * 9;
             if (c.packed16 && use_s16 && k_fits && (double)H * W * 64.0 < 4294967296.0) {
                 a.s16 = 1; a.wpk16 = c.packed16; a.nchunks16 = c.nchunks16;
+                if (fuse16) a.wmix16 = mixf->packed16;
                 const int need = (a.grid + 7) / 8 * 8;
                 a.persist = need < persist_wgs ? need : persist_wgs;
             } else if (a.grid > persist_wgs) {

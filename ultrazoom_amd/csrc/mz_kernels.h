@@ -68,6 +68,7 @@ struct ConvArgs {
     int s16;           // persistent launches of 16-bit types: use the 16x16x32-MFMA kernel (needs wpk16)
     const void* wpk16; // weights packed for it: [ntile][32-channel chunk][tap][2*nt][64 lanes][16 B]
     int nchunks16;     // 32-channel chunks
+    const void* wmix16; // EPI_FUSEDMIX on the 16x16x32 kernel: gate weights packed [2*nt K-steps][2*nt][64 lanes][16 B]
     int use_glds;      // stage through global_load_lds (1) or through registers (0)
     unsigned long long* dbg;  // -DMZ_STAMP diagnostic builds: per-stage s_memtime stamps of one workgroup
 };
@@ -95,7 +96,7 @@ struct PackArgs {
     int c0, cp0, c1;   // CONCAT: real/padded channels of in0, real channels of in1;  PLAIN/CRUSH: c0 = cin, cp0 = padded cin
 };
 size_t packed_bytes(int taps, int nt, int ntiles, int nchunks);
-size_t conv16_lds_bytes(int mode, int nt);
+size_t conv16_lds_bytes(int mode, int nt, bool fuse);
 hipError_t launch_pack(const PackArgs& a, hipStream_t s);
 
 // ---- small kernels ----------------------------------------------------------------------------

@@ -1318,51 +1318,54 @@ __device__ __forceinline__ void s16_back(f32x4 (&acc)[4][2 * NT], Frag16& f, uin
 // v_permlane16_swap between the two fragments of a group leaves lane g with one full 16-byte plane entry:
 // fragment (g & 1) of the pair, plane (g >> 1) of that fragment.
 template <class TT, int NT, int MODE, int EPI, bool SILU>
-__device__ __forceinline__ void store_epilogue16(const ConvArgs& a, f32x4 (&acc)[4][2 * NT], int lane, int w, int nbase, int b,
-                                                 int y0, int x0) {
+__device__ __forceinline__ void store_frag16(const ConvArgs& a, f32x4 (&accpf)[2 * NT], const int pf, int lane, int w, int nbase,
+                                             int b, int y0, int x0) {
     using G = Geo<MODE>;
     constexpr bool d2s = EPI == EPI_D2S;
     const int g = lane >> 4, c = lane & 15;
     const long long plane_o = d2s ? (long long)a.Hout * a.Wout * 16 : (long long)a.H * a.W * 16;
     char* const obase = (char*)a.out + (long long)b * a.p_out * plane_o;
+    const int py = G::ROW_PER_WAVE == 2 ? y0 + 2 * w + (pf >> 1) : y0 + w;
+    const int px = G::ROW_PER_WAVE == 2 ? x0 + 16 * (pf & 1) + c : x0 + 16 * pf + c;
+    const bool inside = py < a.H && px < a.W;
 #pragma unroll
-    for (int pf = 0; pf < 4; ++pf) {
-        const int py = G::ROW_PER_WAVE == 2 ? y0 + 2 * w + (pf >> 1) : y0 + w;
-        const int px = G::ROW_PER_WAVE == 2 ? x0 + 16 * (pf & 1) + c : x0 + 16 * pf + c;
-        const bool inside = py < a.H && px < a.W;
+    for (int n = 0; n < NT; ++n) {
+        float v[8];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float ea = acc[pf][2 * n][j], eb = acc[pf][2 * n + 1][j];
-                const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, ea), __builtin_bit_cast(uint32_t, eb),
-                                                                 false, false);
-                const uint32_t s0 = sw[0], s1 = sw[1];
-                v[j] = __builtin_bit_cast(float, s0);
-                v[4 + j] = __builtin_bit_cast(float, s1);
-            }
-            const int cu = 2 * (2 * n + (g & 1)) + (g >> 1);  // 16-byte unit inside this workgroup's BN channels
-            const int nch = nbase + cu * 8;
-            if constexpr (SILU) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = v[j] * sigmoidf_(v[j]);
-            }
-            if (!inside) continue;
-            char* dst;
-            if constexpr (d2s) {
-                if (nch >= 4 * a.cp_out) continue;
-                const int ij = nch / a.cp_out;
-                const int ch = nch - ij * a.cp_out;
-                const int Y = 2 * py + (ij >> 1), X = 2 * px + (ij & 1);
-                dst = obase + (ch >> 3) * plane_o + ((long long)Y * a.Wout + X) * 16;
-            } else {
-                if (nch >= a.cp_out) continue;
-                dst = obase + (nch >> 3) * plane_o + ((long long)py * a.W + px) * 16;
-            }
-            st_unit<TT>(dst, v);
+        for (int j = 0; j < 4; ++j) {
+            const float ea = accpf[2 * n][j], eb = accpf[2 * n + 1][j];
+            const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, ea), __builtin_bit_cast(uint32_t, eb),
+                                                             false, false);
+            const uint32_t s0 = sw[0], s1 = sw[1];
+            v[j] = __builtin_bit_cast(float, s0);
+            v[4 + j] = __builtin_bit_cast(float, s1);
         }
+        const int cu = 2 * (2 * n + (g & 1)) + (g >> 1);  // 16-byte unit inside this workgroup's BN channels
+        const int nch = nbase + cu * 8;
+        if constexpr (SILU) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = v[j] * sigmoidf_(v[j]);
+        }
+        if (!inside) continue;
+        char* dst;
+        if constexpr (d2s) {
+            if (nch >= 4 * a.cp_out) continue;
+            const int ij = nch / a.cp_out;
+            const int ch = nch - ij * a.cp_out;
+            const int Y = 2 * py + (ij >> 1), X = 2 * px + (ij & 1);
+            dst = obase + (ch >> 3) * plane_o + ((long long)Y * a.Wout + X) * 16;
+        } else {
+            if (nch >= a.cp_out) continue;
+            dst = obase + (nch >> 3) * plane_o + ((long long)py * a.W + px) * 16;
+        }
+        st_unit<TT>(dst, v);
     }
+}
+template <class TT, int NT, int MODE, int EPI, bool SILU>
+__device__ __forceinline__ void store_epilogue16(const ConvArgs& a, f32x4 (&acc)[4][2 * NT], int lane, int w, int nbase, int b,
+                                                 int y0, int x0) {
+#pragma unroll
+    for (int pf = 0; pf < 4; ++pf) store_frag16<TT, NT, MODE, EPI, SILU>(a, acc[pf], pf, lane, w, nbase, b, y0, x0);
 }
 
 // -DMZ_STAMP=2 diagnostic build: where the waves of one workgroup spend each half-chunk (tools/stamp_probe16.py)
@@ -1378,10 +1381,65 @@ __device__ __forceinline__ void store_epilogue16(const ConvArgs& a, f32x4 (&acc)
 #else
 #define S16STAMP(u, k) do { } while (0)
 #endif
-template <class TT, int NT, int MODE>
+// gate GEMM of the fused mix on the 16x16 layout: 2 NT K-steps of NF = 2 NT weight fragments each, walked in HALF
+// steps of NT fragments: the next half step's fragments are requested before the current one's MFMAs are issued
+// (LDS reads return in order: lgkmcnt(NT) = "everything but the NT reads just requested has landed").
+template <int NT, int H, int I> __device__ __forceinline__ void gate_reads(u32x4 (&wv)[NT], uint32_t addr) {
+    if constexpr (I < NT) {
+        constexpr int ks = H >> 1, part = H & 1;
+        wv[I] = lds_read128<(ks * 2 * NT + part * NT + I) * 1024>(addr);
+        gate_reads<NT, H, I + 1>(wv, addr);
+    }
+}
+template <int NT, int N> __device__ __forceinline__ void gate_wait(u32x4 (&wv)[NT]) {
+    if constexpr (NT == 1) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(wv[0]) : "n"(N) : "memory");
+    else if constexpr (NT == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(wv[0]), "+v"(wv[1]) : "n"(N) : "memory");
+    else asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]) : "n"(N) : "memory");
+}
+template <class TT, int NT, int H>
+__device__ __forceinline__ void gate_halves(f32x4 (&beta)[2 * NT], const u32x4 (&xf)[NT], const u32x4 (&zf)[NT], u32x4 (&wa)[NT],
+                                            u32x4 (&wb)[NT], uint32_t addr) {
+    if constexpr (H < 4 * NT) {
+        constexpr int ks = H >> 1, part = H & 1;
+        constexpr bool more = H + 1 < 4 * NT;
+        if constexpr (more) gate_reads<NT, H + 1, 0>(wb, addr);  // wa = this half step's fragments, wb = the next one's
+        gate_wait<NT, (more ? NT : 0)>(wa);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            if constexpr (ks < NT) mma16<TT>(beta[part * NT + i], wa[i], xf[ks]);
+            else mma16<TT>(beta[part * NT + i], wa[i], zf[ks - NT]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        gate_halves<TT, NT, H + 1>(beta, xf, zf, wb, wa, addr);
+    }
+}
+
+// FUSE: conv2 + AdaptiveResidualMix (model.py:826-839) in one pass, as in conv3w_kernel<.., FUSE> but on the 16x16
+// accumulator layout: after the K loop the wave packs z into MFMA B operands (two 16-channel accumulator fragments =
+// one 32-wide K step; the gate weights were packed in that order, SRC_MIXF + frag16), two extra barriers let the
+// weight loader drop the 4 NT^2 KB of gate weights into the second weight slot (+ the LDS behind it) once every wave
+// has left the K loop, x arrives as plain 16-byte loads (the plane-major layout IS the B-operand layout), and the
+// blend x + sigmoid(alpha) sigmoid(beta) (z - x) runs in the accumulator registers before the common store.
+template <class TT> __device__ __forceinline__ void unpack2(uint32_t v, float& lo, float& hi) {
+    if constexpr (TT::IS_BF16) {
+        lo = __builtin_bit_cast(float, v << 16);
+        hi = __builtin_bit_cast(float, v & 0xffff0000u);
+    } else {
+        lo = (float)__builtin_bit_cast(_Float16, (uint16_t)(v & 0xffff));
+        hi = (float)__builtin_bit_cast(_Float16, (uint16_t)(v >> 16));
+    }
+}
+template <class TT> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    if constexpr (TT::IS_BF16) return pack_bf16(lo, hi);
+    else return pack_f16(lo, hi);
+}
+
+template <class TT, int NT, int MODE, bool FUSE>
 __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
     using G = Geo<MODE>;
     constexpr int NF = 2 * NT;
+    constexpr int MIX_PIECES = 4 * NT * NT;  // FUSE: gate weights = 2 NT K-steps x NF fragments of 1 KiB
     constexpr int BN = 32 * NT;
     constexpr int A_PLANE = G::PLANE;
     constexpr int A_SLOT = 4 * A_PLANE;
@@ -1427,7 +1485,6 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
             int mt_, nt_;
             for (int i = cur; i < cnt; i = seek(i + step, mt_, nt_)) ++ntl;
         }
-        const int total = ntl * nchunks * 2;  // half-chunks = barriers
         int l_pos = cur;
         bool l_ok = true;
         if (w == 9) {
@@ -1457,14 +1514,26 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
                 }
             };
             issue();
-            for (int u = 0; u < total; ++u) {
-                S16STAMP(u, 0);
-                wait_vmcnt<0>();
-                S16STAMP(u, 1);
-                __builtin_amdgcn_s_barrier();
-                S16STAMP(u, 2);
-                issue();
-                S16STAMP(u, 3);
+            int u = 0;
+            for (int t = 0; t < ntl; ++t) {
+                for (int hh = 0; hh < 2 * nchunks; ++hh, ++u) {
+                    S16STAMP(u, 0);
+                    wait_vmcnt<0>();
+                    S16STAMP(u, 1);
+                    __builtin_amdgcn_s_barrier();
+                    S16STAMP(u, 2);
+                    issue();
+                    S16STAMP(u, 3);
+                }
+                if constexpr (FUSE) {
+                    __builtin_amdgcn_s_barrier();  // E1: every wave has left the K loop: the second weight slot is free
+                    const char* msrc = (const char*)a.wmix16 + lane * 16;
+                    char* mdst = smem + B_BASE + B_SLOT;
+#pragma unroll
+                    for (int j = 0; j < MIX_PIECES; ++j) glds16(msrc + j * 1024, mdst + j * 1024);
+                    wait_vmcnt<0>();
+                    __builtin_amdgcn_s_barrier();  // E2: the gate weights have landed
+                }
             }
         } else {
             // ---- halo loader: one 4-plane image per 32-channel chunk, one chunk ahead.  Buffer-addressed LDS-DMA: the
@@ -1511,14 +1580,21 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
                 }
             };
             issue();
-            for (int u = 0; u < total; ++u) {
-                S16STAMP(u, 0);
-                if ((u & 1) == 0) wait_vmcnt<0>();  // a chunk's first barrier publishes its halo image
-                S16STAMP(u, 1);
-                __builtin_amdgcn_s_barrier();
-                S16STAMP(u, 2);
-                if ((u & 1) == 0) issue();          // chunk c + 1 -> the slot chunk c - 1 was read from
-                S16STAMP(u, 3);
+            int u = 0;
+            for (int t = 0; t < ntl; ++t) {
+                for (int hh = 0; hh < 2 * nchunks; ++hh, ++u) {
+                    S16STAMP(u, 0);
+                    if ((hh & 1) == 0) wait_vmcnt<0>();  // a chunk's first barrier publishes its halo image
+                    S16STAMP(u, 1);
+                    __builtin_amdgcn_s_barrier();
+                    S16STAMP(u, 2);
+                    if ((hh & 1) == 0) issue();          // chunk c + 1 -> the slot chunk c - 1 was read from
+                    S16STAMP(u, 3);
+                }
+                if constexpr (FUSE) {
+                    __builtin_amdgcn_s_barrier();  // E1
+                    __builtin_amdgcn_s_barrier();  // E2
+                }
             }
         }
         return;
@@ -1564,6 +1640,78 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
             const uint32_t tmp = a_cur; a_cur = a_oth; a_oth = tmp;
         }
         const int nbase = ntile * BN;
+        if constexpr (FUSE) {
+            // ---- AdaptiveResidualMix in registers: acc = z (conv2 output), x = a.in1 (the block input) ----
+            u32x4 zb[4][NT];  // z as B operands: K step m = accumulator fragments 2m, 2m+1 (rounded to the storage type)
+#pragma unroll
+            for (int pf = 0; pf < 4; ++pf)
+#pragma unroll
+                for (int m = 0; m < NT; ++m) {
+                    const f32x4 za = acc[pf][2 * m], zc = acc[pf][2 * m + 1];
+                    u32x4 t;
+                    t[0] = pack2<TT>(za[0], za[1]); t[1] = pack2<TT>(za[2], za[3]);
+                    t[2] = pack2<TT>(zc[0], zc[1]); t[3] = pack2<TT>(zc[2], zc[3]);
+                    asm volatile("" : "+v"(t));  // opaque: no pack -> unpack forwarding that would keep 96 floats alive
+                    zb[pf][m] = t;
+                }
+            const long long hw = (long long)a.H * a.W;
+            const char* const xim = (const char*)a.in1 + (long long)b * a.p1 * hw * 16;
+            const uint32_t mix_lane = lds_base + B_BASE + B_SLOT + lane * 16;
+            // x as B operands (plane 4 kc + g of the lane's pixel): requested one pixel fragment ahead of its use
+            auto x_ptr = [&](int pf, bool& inside) __attribute__((always_inline)) {
+                const int py = G::ROW_PER_WAVE == 2 ? y0 + 2 * w + (pf >> 1) : y0 + w;
+                const int px = G::ROW_PER_WAVE == 2 ? x0 + 16 * (pf & 1) + c : x0 + 16 * pf + c;
+                inside = py < a.H && px < a.W;
+                return xim + ((long long)py * a.W + px) * 16;
+            };
+            auto load_xf = [&](int pf, u32x4 (&xf)[NT]) __attribute__((always_inline)) {
+                bool inside;
+                const char* const xp = x_ptr(pf, inside);
+#pragma unroll
+                for (int kc = 0; kc < NT; ++kc) {
+                    xf[kc] = u32x4{0u, 0u, 0u, 0u};
+                    if (inside && 4 * kc + g < a.p1) xf[kc] = *(const u32x4*)(xp + (long long)(4 * kc + g) * hw * 16);
+                }
+            };
+            u32x4 xfa[NT], xfb[NT];
+            load_xf(0, xfa);
+            __builtin_amdgcn_s_barrier();  // E1
+            __builtin_amdgcn_s_barrier();  // E2: gate weights are in LDS
+#pragma unroll
+            for (int pf = 0; pf < 4; ++pf) {
+                __builtin_amdgcn_sched_barrier(0);
+                u32x4 (&xf)[NT] = (pf & 1) ? xfb : xfa;
+                if (pf + 1 < 4) load_xf(pf + 1, (pf & 1) ? xfa : xfb);
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) acc[pf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+                // gate: beta = Wx . x + Wz . z   (K steps 0..NT-1 = x, NT..2NT-1 = z)
+                u32x4 wa[NT], wb[NT];
+                gate_reads<NT, 0, 0>(wa, mix_lane);
+                gate_halves<TT, NT, 0>(acc[pf], xf, zb[pf], wa, wb, mix_lane);
+                // x again, in accumulator layout (channels 16 nf + 4 g .. + 3): the lines were just fetched above
+                bool inside;
+                const char* const xp = x_ptr(pf, inside);
+                uint2 xq[NF];
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) {
+                    xq[nf] = make_uint2(0u, 0u);
+                    if (inside && 2 * nf + (g >> 1) < a.p1) xq[nf] = *(const uint2*)(xp + (long long)(2 * nf + (g >> 1)) * hw * 16 + (g & 1) * 8);
+                }
+                // blend, in place: out = x + sigmoid(alpha) * sigmoid(beta) * (z - x)
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) {
+                    float zv[4], xv[4];
+                    unpack2<TT>(zb[pf][nf >> 1][(nf & 1) * 2], zv[0], zv[1]);
+                    unpack2<TT>(zb[pf][nf >> 1][(nf & 1) * 2 + 1], zv[2], zv[3]);
+                    unpack2<TT>(xq[nf].x, xv[0], xv[1]);
+                    unpack2<TT>(xq[nf].y, xv[2], xv[3]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[pf][nf][j] = xv[j] + a.mix_scale * sigmoidf_(acc[pf][nf][j]) * (zv[j] - xv[j]);
+                }
+                store_frag16<TT, NT, MODE, EPI_STORE, false>(a, acc[pf], pf, lane, w, nbase, b, y0, x0);
+            }
+        } else
         if (a.epi == EPI_D2S) store_epilogue16<TT, NT, MODE, EPI_D2S, false>(a, acc, lane, w, nbase, b, y0, x0);
         else if (a.silu) store_epilogue16<TT, NT, MODE, EPI_STORE, true>(a, acc, lane, w, nbase, b, y0, x0);
         else store_epilogue16<TT, NT, MODE, EPI_STORE, false>(a, acc, lane, w, nbase, b, y0, x0);
@@ -1748,9 +1896,11 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
 }
 
 // the 16x16x32 kernel: two 4-plane halo images + the two halves of a chunk's weights
-size_t conv16_lds_bytes(int mode, int nt) {
+size_t conv16_lds_bytes(int mode, int nt, bool fuse) {
     const size_t a_slot = 4 * (size_t)(mode == MODE_C3W16 ? 640 : 672) * 16;
-    return 2 * a_slot + 2 * (size_t)(2 * ((9 * nt + 1) / 2) * 1024);
+    const size_t b_slot = 2 * (size_t)((9 * nt + 1) / 2) * 1024;
+    const size_t gate = fuse ? (size_t)4 * nt * nt * 1024 : 0;  // lives in the second weight slot and the LDS behind it
+    return 2 * a_slot + b_slot + (gate > b_slot ? gate : b_slot);
 }
 
 size_t conv_lds_bytes(int mode, int nt) {
@@ -1789,11 +1939,16 @@ template <class TT, int NT, int MODE> static hipError_t launch_one(const ConvArg
     const size_t lds = conv_lds_bytes(MODE, NT);
     if constexpr (MODE == MODE_C3W16 || MODE == MODE_C3W8) {
         if constexpr (NT <= 3) {
-            if (a.epi == EPI_FUSEDMIX)
+            if (a.epi == EPI_FUSEDMIX && a.persist > 0 && a.s16) {
+                if constexpr (TT::SZ == 2)
+                    hipLaunchKernelGGL((conv3s_kernel<TT, NT, MODE, true>), dim3(a.persist), dim3(640), conv16_lds_bytes(MODE, NT, true), s, a);
+                else
+                    return hipErrorInvalidValue;
+            } else if (a.epi == EPI_FUSEDMIX)
                 hipLaunchKernelGGL((conv3w_kernel<TT, NT, MODE, true>), dim3(a.grid), dim3(576), lds, s, a);
             else if (a.persist > 0 && a.s16 && (a.epi == EPI_STORE || a.epi == EPI_D2S)) {
                 if constexpr (TT::SZ == 2)
-                    hipLaunchKernelGGL((conv3s_kernel<TT, NT, MODE>), dim3(a.persist), dim3(640), conv16_lds_bytes(MODE, NT), s, a);
+                    hipLaunchKernelGGL((conv3s_kernel<TT, NT, MODE, false>), dim3(a.persist), dim3(640), conv16_lds_bytes(MODE, NT, false), s, a);
                 else
                     return hipErrorInvalidValue;
             } else if (a.persist > 0 && (a.epi == EPI_STORE || a.epi == EPI_D2S))
@@ -1846,8 +2001,11 @@ template <class TT, int NT, int MODE> static hipError_t set_lds_one() {
         e = hipFuncSetAttribute((const void*)conv3p_kernel<TT, NT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return e;
         if constexpr (TT::SZ == 2) {
-            e = hipFuncSetAttribute((const void*)conv3s_kernel<TT, NT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)conv16_lds_bytes(MODE, NT));
+            e = hipFuncSetAttribute((const void*)conv3s_kernel<TT, NT, MODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)conv16_lds_bytes(MODE, NT, false));
+            if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute((const void*)conv3s_kernel<TT, NT, MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)conv16_lds_bytes(MODE, NT, true));
             if (e != hipSuccess) return e;
         }
         return hipFuncSetAttribute((const void*)conv3w_kernel<TT, NT, MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1918,6 +2076,19 @@ template <class TT> __global__ void pack_kernel(const PackArgs a, long long tota
         const int k = kc * CK + kin;
         if (k < a.cp0) ci = k < a.c0 ? k : -1;
         else ci = (k - a.cp0) < a.c1 ? a.c0 + (k - a.cp0) : -1;
+    } else if (a.in_map == SRC_MIXF && a.frag16) {
+        // fused gate for the 16x16x32 kernel: K-steps [0, ncx) = x channels in natural order (32 per step); then one
+        // K-step per PAIR of 16-channel accumulator fragments of z, K elements in the order the accumulator quads of
+        // lane group g = lane >> 4 supply them: e < 4 -> fragment 2m, channel 4g + e; e >= 4 -> fragment 2m + 1
+        const int ncx = (a.cp0 + 31) / 32;
+        if (kc < ncx) {
+            const int k = kc * 32 + kin;
+            ci = k < a.c0 ? k : -1;
+        } else {
+            const int m = kc - ncx, g = lane >> 4;
+            const int zch = 32 * m + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4));
+            ci = zch < a.c1 ? a.c0 + zch : -1;
+        }
     } else if (a.in_map == SRC_MIXF) {
         // fused AdaptiveResidualMix gate: chunks [0, ncx) = x channels in natural order; then one chunk per
         // (32-row accumulator tile, fragment g) of z, K-elements in ACCUMULATOR ROW order (ZFrag<TT>::make)
