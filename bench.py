@@ -227,7 +227,7 @@ def main():
         conv_tflops = prof["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12 if prof["conv_ms"] > 0 else 0.0
         peak = PEAK_TFLOPS[args.dtype]
         result = {
-            "metric": "upscaled MPix/sec, MewZoom-4X 1080p bf16 batched inference" if args.workload.startswith("cfg3")
+            "metric": f"upscaled MPix/sec, MewZoom-4X 1080p {args.dtype} batched inference" if args.workload.startswith("cfg3")
             else "upscaled MPix/sec",
             "value": value,
             "unit": "MPix/s",
