@@ -189,3 +189,44 @@ def test_uint8_io_matches_float_path_with_save_image_rounding(dtype):
     y = m.upscale((xu.float() / 255).to("cuda", dtype)).float()
     if dtype == torch.float32:
         assert torch.equal(got.cpu(), (y * 255 + 0.5).clamp(0, 255).to(torch.uint8).cpu())
+
+
+# Channel counts chosen to reach every kernel variant: (primary channels, hidden ratio) -> fused mix on the 16x16x32 kernel
+# with NT = 1, 2, 3 (C = 32, 64, 96), K that pads to 32-channel chunks with a half-zero last chunk (C = 80 -> conv2 K = 160),
+# K that does not fit the 16x16x32 kernel (C = 24, 48 with hidden ratio 1 -> 32x32x16 kernels), two N tiles (hidden 4 x 48).
+FUZZ_CONFIGS = [
+    # ratio, channels (4 levels), layers, hidden ratio, (B, H, W)
+    (2, (32, 64, 96, 128), (2, 2, 2, 2), 2, (2, 40, 72)),
+    (2, (96, 96, 96, 96), (2, 2, 2, 2), 2, (1, 33, 47)),
+    (2, (80, 48, 24, 16), (2, 2, 2, 2), 2, (1, 48, 64)),
+    (4, (48, 24, 32, 64), (2, 2, 2, 2), 4, (1, 24, 40)),
+    (2, (48, 96, 16, 32), (2, 3, 2, 2), 1, (3, 17, 29)),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("spec", FUZZ_CONFIGS)
+def test_mixed_channel_configs_against_oracle(spec, dtype):
+    """Configurations the golden fixtures do not hold, checked against the CPU oracle (itself pinned by the fixtures)."""
+    r, ch, layers, hr, (B, H, W) = spec
+    names = ("primary", "secondary", "tertiary", "quaternary")
+    cfg = {"upscale_ratio": r, "hidden_ratio": hr, "num_deg_features": 3}
+    for n, c, l in zip(names, ch, layers):
+        cfg[f"{n}_channels"] = c
+        cfg[f"{n}_layers"] = l
+    sd = synth_state_dict(oracle.parameter_shapes(cfg), seed=sum(ch) + hr)
+    x = synth_image(B, H, W, seed=H * W)
+    m = build(cfg, sd, dtype)
+    with torch.inference_mode():
+        want_sr, want_qa = oracle.forward(cfg, sd, x)
+        sr, qa = m.forward(x.to("cuda", dtype))
+    sr = sr.float().cpu()
+    err = (sr - want_sr).abs().max().item()
+    qa_err = (qa.float().cpu() - want_qa).abs().max().item()
+    if dtype == torch.float32:
+        assert err <= F32_TOL and qa_err <= F32_TOL, (err, qa_err)
+    else:
+        gate = LOWP[dtype]
+        p = psnr(sr.clamp(0, 1), want_sr.clamp(0, 1))
+        print(f"{spec} {dtype}: max-abs {err:.3e} psnr {p:.1f} dB qa {qa_err:.3e}")
+        assert err <= gate["max_abs"] and p >= gate["psnr"] and qa_err <= gate["qa"], (err, p, qa_err)
