@@ -9,8 +9,31 @@ if str(REPO) not in sys.path:
     sys.path.insert(0, str(REPO))
 
 
+def host_cores() -> int:
+    """CPU cores this process may really use: affinity mask AND cgroup quota (a GPU box shows 256 CPUs in the affinity
+    mask of a 16-core container; 256 oracle threads on 16 cores run the CPU checker ~40x slower)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    try:
+        import torch
+
+        torch.set_num_threads(host_cores())  # the CPU oracle is the checker in most tests
+    except Exception:  # noqa: BLE001
+        pass
 
 
 def pytest_collection_modifyitems(config, items):

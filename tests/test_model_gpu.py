@@ -13,6 +13,7 @@ import os
 import pytest
 import torch
 
+from conftest import host_cores
 from golden_util import MODEL_CASES, GoldenCase, psnr
 from oracle import mewzoom_oracle as oracle
 from ultrazoom_amd import MewZoom
@@ -96,7 +97,7 @@ def test_cfg2_full_size_540p_against_oracle():
     floor / zero-pad path runs) on ONE image, f32 and bf16, against the CPU oracle at full size."""
     sd = synth_state_dict(oracle.parameter_shapes(CFG2), 21)
     x = synth_image(1, 540, 960, 22)
-    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    torch.set_num_threads(host_cores())
     with torch.inference_mode():
         want = oracle.upscale(CFG2, sd, x)
     m = build(CFG2, sd, torch.float32)
@@ -116,7 +117,7 @@ def test_cfg3_model_reduced_size_against_oracle_and_full_size_properties():
     image on CPU, so: direct parity at 1/16 of the pixels, then size-independent properties at 1080p."""
     sd = synth_state_dict(oracle.parameter_shapes(CFG3), 31)
     x = synth_image(1, 136, 240, 32)
-    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    torch.set_num_threads(host_cores())
     with torch.inference_mode():
         want = oracle.upscale(CFG3, sd, x)
     m = build(CFG3, sd, torch.float32)
@@ -153,7 +154,7 @@ def test_cfg5_substitute_4k_single_image_fp16():
     sd = synth_state_dict(oracle.parameter_shapes(CFG2), 41)
     x = synth_image(1, 2160, 3840, 42)
     ch, cw, margin = 768, 1024, 224
-    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    torch.set_num_threads(host_cores())
     with torch.inference_mode():
         want = oracle.upscale(CFG2, sd, x[:, :, :ch, :cw])[:, :, : 2 * (ch - margin), : 2 * (cw - margin)]
     m = build(CFG2, sd, torch.float16)
