@@ -231,3 +231,29 @@ def test_mixed_channel_configs_against_oracle(spec, dtype):
         p = psnr(sr.clamp(0, 1), want_sr.clamp(0, 1))
         print(f"{spec} {dtype}: max-abs {err:.3e} psnr {p:.1f} dB qa {qa_err:.3e}")
         assert err <= gate["max_abs"] and p >= gate["psnr"] and qa_err <= gate["qa"], (err, p, qa_err)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_kernel_variants_agree(dtype, monkeypatch):
+    """The same forward under every kernel selection the library can make (environment knobs of INTEGRATION.md section 5):
+    each one meets the gate against the oracle, and the variants differ from each other by rounding only."""
+    case = GoldenCase("g9_4x_c32")  # C = 32, 64: fused mix at two levels; 4X head
+    sd = case.weights()
+    x = synth_image(2, 48, 80, seed=77)
+    with torch.inference_mode():
+        want = oracle.upscale(case.config, sd, x)
+    m = build(case, sd, dtype)
+    xg = x.to("cuda", dtype)
+    outs = {}
+    for name, env in {"default": {}, "no_fuse16": {"MZ_NO_FUSE16": "1"}, "no_fuse": {"MZ_NO_FUSE": "1"},
+                      "no_s16": {"MZ_NO_S16": "1"}, "no_persist": {"MZ_NO_PERSIST": "1"}, "no_wide": {"MZ_NO_WIDE": "1"}}.items():
+        for k in ("MZ_NO_FUSE16", "MZ_NO_FUSE", "MZ_NO_S16", "MZ_NO_PERSIST", "MZ_NO_WIDE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        outs[name] = m.upscale(xg).float().cpu()
+    gate = LOWP[dtype]
+    for name, y in outs.items():
+        err = (y - want).abs().max().item()
+        assert err <= gate["max_abs"] and psnr(y, want) >= gate["psnr"], (name, err)
+        assert (y - outs["default"]).abs().max().item() <= gate["max_abs"], name
