@@ -163,7 +163,9 @@ def test_pixel_crush(dt, case):
     assert err < OP_TOL[dt], f"max-abs {err}"
 
 
-MIX_CASES = [(2, 7, 9, 16), (1, 16, 17, 24), (1, 20, 33, 48), (2, 8, 40, 96), (1, 5, 13, 128), (1, 3, 50, 384)]
+MIX_CASES = [(2, 7, 9, 16), (1, 16, 17, 24), (1, 20, 33, 48), (2, 8, 40, 96), (1, 5, 13, 128), (1, 3, 50, 384),
+             # C = k * 192: the 16-bit types run mix16_kernel (192-channel N tiles, x / z straight into MFMA operands)
+             (1, 9, 40, 192), (3, 7, 23, 192), (2, 11, 29, 384), (1, 10, 27, 768)]
 
 
 @pytest.mark.parametrize("dt", list(DTYPES))

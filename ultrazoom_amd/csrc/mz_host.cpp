@@ -107,6 +107,11 @@ static void plan_conv(ConvW& c, int dtype, int mode, int cout, int cin, int kh, 
         c.nchunks16 = (c.cp0 + 31) / 32;
         c.packed16_sz = packed_bytes(c.taps, 2 * c.nt, c.ntiles, c.nchunks16);
     }
+    // AdaptiveResidualMix with C = k * 192: second packing for mix16_kernel (192-channel N tiles = 12 fragments of 16)
+    if (mode == MODE_GEMM1 && dtype != DT_F32 && in_map == SRC_CONCAT && cout % 192 == 0 && c0 == cout && c1 == cout) {
+        c.nchunks16 = 2 * cout / 32;
+        c.packed16_sz = packed_bytes(1, 12, cout / 192, c.nchunks16);
+    }
 }
 
 struct BlockW {
@@ -362,6 +367,7 @@ static int pack_conv(ConvW& c, int dtype, const float* w_dev, hipStream_t s) {
     if (c.packed16_sz) {
         if (!c.packed16) HIPCHK(hipMalloc(&c.packed16, c.packed16_sz));
         p.dst = c.packed16; p.frag16 = 1; p.nchunks = c.nchunks16;
+        if (c.in_map == SRC_CONCAT) { p.nt = 6; p.ntiles = c.cout / 192; }  // mix16_kernel: 12 fragments per K step
         HIPCHK(launch_pack(p, s));
     }
     c.set = true;
@@ -693,11 +699,19 @@ struct Runner {
         a.cp_out = pad16(c.cout);
         a.p_out = a.cp_out * sz / 16;
         a.mix_scale = 1.0f / (1.0f + std::exp(-alpha));
-        pick_order(a, c, (double)npix * (c.cp0 + pad16(c.c1)) * sz, 64);
+        const bool mix16 = c.packed16 != nullptr && getenv("MZ_NO_MIX16") == nullptr &&
+                           (double)npix * c.cp0 * sz < 4294967296.0;  // 32-bit buffer offsets inside each tensor
+        if (mix16) {  // 192-channel N tiles, x / z straight into MFMA operands (mix16_kernel)
+            a.ntiles = c.cout / 192;
+            a.wpk16 = c.packed16;
+            a.nchunks16 = c.nchunks16;
+        }
+        pick_order(a, c, (double)npix * (c.cp0 + pad16(c.c1)) * sz, mix16 ? 32 : 64);
         ProfRec* r;
         prof_begin(r, 2.0 * (double)npix * c.cin * c.cout, (double)npix * 3.0 * c.cout * sz, 0);
         if (r) { r->kind = 1; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.gm * 1000 + a.gn; }
-        check(launch_conv(dtype, MODE_GEMM1, c.nt, a, s), "mix launch");
+        if (mix16) check(launch_mix16(dtype, a, s), "mix16 launch");
+        else check(launch_conv(dtype, MODE_GEMM1, c.nt, a, s), "mix launch");
         prof_end(r);
     }
 

@@ -78,6 +78,8 @@ size_t conv_lds_bytes(int mode, int nt);
 int choose_nt(int n_padded);
 int gemm1_chunks_per_stage();
 hipError_t launch_conv(int dtype, int mode, int nt, const ConvArgs& a, hipStream_t s);
+// AdaptiveResidualMix for C = k * 192 on the 16x16x32 MFMA (16-bit types): a.wpk16 / a.nchunks16 = K steps over [x ; z]
+hipError_t launch_mix16(int dtype, const ConvArgs& a, hipStream_t s);
 hipError_t init_kernels();  // raises the dynamic-LDS limits once per process
 
 // ---- weight packing ---------------------------------------------------------------------------

@@ -1719,6 +1719,197 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
     }
 }
 
+// ================================================================================================
+// mix16_kernel: AdaptiveResidualMix (model.py:826-839) for C = k * 192 channels on the 16x16x32 MFMA (16-bit types).
+//   out = x + sigmoid(alpha) * sigmoid(W [x ; z]) * (z - x),   W: [C, 2C]
+// The 1x1 gate GEMM has no tap reuse, so it lives on activation traffic: the general 1x1 kernel stages x and z through
+// LDS once per 96-channel N tile.  Here (a) an N tile is 192 channels (half the passes over x and z), and (b) x and z never
+// touch LDS: in the plane-major layout a lane's 16 bytes of plane 4 ks + g of pixel c ARE its B-operand fragment of
+// K step ks, so they are plain global loads, requested three K steps ahead.  Only the weights (12 KB per K step, shared
+// by the 8 compute waves) go through LDS: a loader wave streams stages of 4 K steps into two slots.
+// Workgroup = 256 pixels x 192 channels: wave w owns pixels 32 w .. 32 w + 31 (two 16-pixel fragments) x 12 channel
+// fragments = 96 accumulator registers; weight pairs are read two 4-MFMA groups ahead with counted lgkmcnt.
+// ================================================================================================
+struct MixFrag {
+    u32x4 w[3][2];
+};
+template <class TT, int G>  // group G of a stage: K step G / 6, channel-fragment pair G % 6
+__device__ __forceinline__ void mix16_group(f32x4 (&acc)[2][12], MixFrag& f, const u32x4 (&xb)[2], uint32_t b_addr) {
+    constexpr int n = G % 6, wp = G % 3;
+    // request the pair of group G + 2 (same stage), then this group's four MFMAs
+    if constexpr (G + 2 < 24) {
+        f.w[(G + 2) % 3][0] = lds_read128<(((G + 2) / 6) * 12 + 2 * ((G + 2) % 6)) * 1024>(b_addr);
+        f.w[(G + 2) % 3][1] = lds_read128<(((G + 2) / 6) * 12 + 2 * ((G + 2) % 6) + 1) * 1024>(b_addr);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mma16<TT>(acc[0][2 * n], f.w[wp][0], xb[0]);
+    mma16<TT>(acc[1][2 * n], f.w[wp][0], xb[1]);
+    mma16<TT>(acc[0][2 * n + 1], f.w[wp][1], xb[0]);
+    mma16<TT>(acc[1][2 * n + 1], f.w[wp][1], xb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (G + 1 < 24) wait_w16<(G + 2 < 24 ? 2 : 0)>(f.w[(G + 1) % 3][0], f.w[(G + 1) % 3][1]);
+}
+template <class TT, int KS> __device__ __forceinline__ void mix16_kstep(f32x4 (&acc)[2][12], MixFrag& f, const u32x4 (&xb)[2], uint32_t b_addr) {
+    mix16_group<TT, KS * 6 + 0>(acc, f, xb, b_addr);
+    mix16_group<TT, KS * 6 + 1>(acc, f, xb, b_addr);
+    mix16_group<TT, KS * 6 + 2>(acc, f, xb, b_addr);
+    mix16_group<TT, KS * 6 + 3>(acc, f, xb, b_addr);
+    mix16_group<TT, KS * 6 + 4>(acc, f, xb, b_addr);
+    mix16_group<TT, KS * 6 + 5>(acc, f, xb, b_addr);
+}
+
+template <class TT>
+__global__ __launch_bounds__(576) void mix16_kernel(const ConvArgs a) {
+    constexpr int STAGE = 4 * 12 * 1024;  // 4 K steps x 12 fragments
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7 compute, 8 = weight loader
+    int mtile, ntile;
+    if (!map_tile(a, mtile, ntile)) return;
+    const int nsteps = a.nchunks16;  // K steps of 32 channels over [x ; z]; a multiple of 4
+    const int nstages = nsteps >> 2;
+
+    if (w == 8) {
+        const char* src = (const char*)a.wpk16 + (size_t)ntile * nsteps * (12 * 1024) + lane * 16;
+        auto issue = [&](int st) __attribute__((always_inline)) {
+            char* dst = smem + (st & 1) * STAGE;
+#pragma unroll
+            for (int j = 0; j < 48; ++j) glds16(src + (size_t)st * STAGE + j * 1024, dst + j * 1024);
+        };
+        issue(0);
+        for (int st = 0; st < nstages; ++st) {
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();            // stage st landed; everyone has finished stage st - 1
+            if (st + 1 < nstages) issue(st + 1);
+        }
+        return;
+    }
+
+    const int g = lane >> 4, c = lane & 15;
+    const long long hw = (long long)a.Ho * a.Wo;
+    const long long M = (long long)a.B * hw;
+    const int half_steps = nsteps >> 1;  // K steps of x (= of z)
+    // Buffer-addressed loads: one descriptor per tensor (the host guarantees < 4 GiB), this lane's pixel as a 32-bit byte
+    // offset of its plane g (0xffffffff = beyond the tensor: the range check returns zeros), the K step as a scalar offset.
+    const uint32_t tensor_bytes = (uint32_t)((long long)a.B * a.p0 * hw * 16);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.in0, 0, (int)tensor_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc((void*)a.in1, 0, (int)tensor_bytes, 0x00020000);
+    uint32_t voff[2];   // (image, plane g, pixel) -> bytes
+    uint32_t vpix[2];   // (image, plane 0, pixel) -> bytes, for the epilogue
+#pragma unroll
+    for (int pf = 0; pf < 2; ++pf) {
+        const long long m = (long long)mtile * 256 + 32 * w + 16 * pf + c;
+        const bool in = m < M;
+        const long long mm = in ? m : 0;
+        const int bimg = (int)(mm / hw);
+        const long long pix = mm - (long long)bimg * hw;
+        vpix[pf] = in ? (uint32_t)((((long long)bimg * a.p0) * hw + pix) * 16) : 0xffffffffu;
+        voff[pf] = in ? (uint32_t)((((long long)bimg * a.p0 + g) * hw + pix) * 16) : 0xffffffffu;
+    }
+    const uint32_t step_bytes = (uint32_t)(4 * hw * 16);  // four planes per K step
+    auto load_b = [&](int ks, u32x4 (&xb)[2]) __attribute__((always_inline)) {  // B operands of K step ks (zeros past the end)
+        const bool isz = ks >= half_steps;
+        const int kk = ks >= nsteps ? 0 : (isz ? ks - half_steps : ks);
+        const int so = __builtin_amdgcn_readfirstlane((int)(kk * step_bytes));
+#pragma unroll
+        for (int pf = 0; pf < 2; ++pf)
+            xb[pf] = isz ? __builtin_amdgcn_raw_buffer_load_b128(zr, (int)voff[pf], so, 0)
+                         : __builtin_amdgcn_raw_buffer_load_b128(xr, (int)voff[pf], so, 0);
+    };
+    f32x4 acc[2][12];
+#pragma unroll
+    for (int pf = 0; pf < 2; ++pf)
+#pragma unroll
+        for (int nf = 0; nf < 12; ++nf) acc[pf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t b_lane = lds_base + lane * 16;
+    // B operands two K steps ahead in three rotating buffers; the stage loop is unrolled three times so that the
+    // rotation (12 K steps = 4 turns) is static -- the K-step count is a multiple of 12 whenever C is one of 192
+    u32x4 xb0[2], xb1[2], xb2[2];
+    load_b(0, xb0);
+    load_b(1, xb1);
+    MixFrag f;
+    auto stage_head = [&](uint32_t b_addr) __attribute__((always_inline)) {
+        __builtin_amdgcn_s_barrier();
+        f.w[0][0] = lds_read128<0>(b_addr);
+        f.w[0][1] = lds_read128<1024>(b_addr);
+        f.w[1][0] = lds_read128<2048>(b_addr);
+        f.w[1][1] = lds_read128<3072>(b_addr);
+        wait_w16<2>(f.w[0][0], f.w[0][1]);
+    };
+    for (int st = 0; st < nstages; st += 3) {
+        const int ks = 4 * st;
+        uint32_t b_addr = b_lane + (st & 1) * STAGE;
+        stage_head(b_addr);
+        load_b(ks + 2, xb2);  mix16_kstep<TT, 0>(acc, f, xb0, b_addr);
+        load_b(ks + 3, xb0);  mix16_kstep<TT, 1>(acc, f, xb1, b_addr);
+        load_b(ks + 4, xb1);  mix16_kstep<TT, 2>(acc, f, xb2, b_addr);
+        load_b(ks + 5, xb2);  mix16_kstep<TT, 3>(acc, f, xb0, b_addr);
+        b_addr = b_lane + ((st + 1) & 1) * STAGE;
+        stage_head(b_addr);
+        load_b(ks + 6, xb0);  mix16_kstep<TT, 0>(acc, f, xb1, b_addr);
+        load_b(ks + 7, xb1);  mix16_kstep<TT, 1>(acc, f, xb2, b_addr);
+        load_b(ks + 8, xb2);  mix16_kstep<TT, 2>(acc, f, xb0, b_addr);
+        load_b(ks + 9, xb0);  mix16_kstep<TT, 3>(acc, f, xb1, b_addr);
+        b_addr = b_lane + (st & 1) * STAGE;
+        stage_head(b_addr);
+        load_b(ks + 10, xb1); mix16_kstep<TT, 0>(acc, f, xb2, b_addr);
+        load_b(ks + 11, xb2); mix16_kstep<TT, 1>(acc, f, xb0, b_addr);
+        load_b(ks + 12, xb0); mix16_kstep<TT, 2>(acc, f, xb1, b_addr);
+        load_b(ks + 13, xb1); mix16_kstep<TT, 3>(acc, f, xb2, b_addr);
+    }
+    // ---- blend and store, one pixel fragment and one channel-fragment pair at a time ----
+    const int nbase = ntile * 192;
+    const uint32_t plane_bytes = (uint32_t)(hw * 16);
+    typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int pf = 0; pf < 2; ++pf) {
+        const bool in = vpix[pf] != 0xffffffffu;
+#pragma unroll
+        for (int n = 0; n < 6; ++n) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int nf = 2 * n + k;
+                const int plane = (nbase >> 3) + 2 * nf + (g >> 1);  // channels nbase + 16 nf + 4 g ..
+                const uint32_t off = in ? vpix[pf] + (uint32_t)plane * plane_bytes + (g & 1) * 8 : 0xffffffffu;
+                const u32x2_ xq = __builtin_amdgcn_raw_buffer_load_b64(xr, (int)off, 0, 0);
+                const u32x2_ zq = __builtin_amdgcn_raw_buffer_load_b64(zr, (int)off, 0, 0);
+                float xv[4], zv[4];
+                unpack2<TT>(xq[0], xv[0], xv[1]); unpack2<TT>(xq[1], xv[2], xv[3]);
+                unpack2<TT>(zq[0], zv[0], zv[1]); unpack2<TT>(zq[1], zv[2], zv[3]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[pf][nf][j] = xv[j] + a.mix_scale * sigmoidf_(acc[pf][nf][j]) * (zv[j] - xv[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float ea = acc[pf][2 * n][j], eb = acc[pf][2 * n + 1][j];
+                const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, ea), __builtin_bit_cast(uint32_t, eb),
+                                                                 false, false);
+                const uint32_t s0 = sw[0], s1 = sw[1];
+                v[j] = __builtin_bit_cast(float, s0);
+                v[4 + j] = __builtin_bit_cast(float, s1);
+            }
+            const int cu = 2 * (2 * n + (g & 1)) + (g >> 1);
+            if (in) st_unit<TT>((char*)a.out + vpix[pf] + (long long)((nbase >> 3) + cu) * plane_bytes, v);
+        }
+    }
+}
+
+hipError_t launch_mix16(int dtype, const ConvArgs& a, hipStream_t s) {
+    if (a.mtiles <= 0 || a.ntiles <= 0 || a.gm <= 0 || a.gn <= 0 || a.grid <= 0 || a.grid >= (1 << 24)) return hipErrorInvalidValue;
+    if (a.nchunks16 <= 0 || a.nchunks16 % 12) return hipErrorInvalidValue;  // three stages of four K steps per loop turn
+    const size_t lds = 2 * 4 * 12 * 1024;
+    switch (dtype) {
+        case DT_BF16: hipLaunchKernelGGL(mix16_kernel<TBF16>, dim3(a.grid), dim3(576), lds, s, a); break;
+        case DT_F16: hipLaunchKernelGGL(mix16_kernel<TF16>, dim3(a.grid), dim3(576), lds, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 template <class TT, int NT, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
     using G = Geo<MODE>;
@@ -2027,6 +2218,8 @@ template <class TT> static hipError_t set_lds_all() {
 }
 hipError_t init_kernels() {
     hipError_t e;
+    if ((e = hipFuncSetAttribute((const void*)mix16_kernel<TBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 12 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)mix16_kernel<TF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 12 * 1024)) != hipSuccess) return e;
     if ((e = set_lds_all<TF32>()) != hipSuccess) return e;
     if ((e = set_lds_all<TBF16>()) != hipSuccess) return e;
     return set_lds_all<TF16>();
@@ -2073,7 +2266,7 @@ template <class TT> __global__ void pack_kernel(const PackArgs a, long long tota
         ty = tap / a.kw;
         tx = tap - ty * a.kw;
     } else if (a.in_map == SRC_CONCAT) {
-        const int k = kc * CK + kin;
+        const int k = kc * ckk + kin;
         if (k < a.cp0) ci = k < a.c0 ? k : -1;
         else ci = (k - a.cp0) < a.c1 ? a.c0 + (k - a.cp0) : -1;
     } else if (a.in_map == SRC_MIXF && a.frag16) {
