@@ -17,16 +17,23 @@ A step = one upscale() of the rank's 16 images plus, when N > 1, the gather of a
 Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
   roofline     : live HIP-event timing of the dominant kernel family (the 3x3 implicit-GEMM convolution):
                  algorithmic FLOPs of all its launches in one step / their summed device time, against the
-                 dense bf16 MFMA peak of 2.5 PFLOP/s.
-  cpu_baseline : the CPU oracle (oracle/mewzoom_oracle.py, torch CPU fp32 on all host cores) timed on a
-                 bounded sample of the same model, with the GPU-vs-oracle PSNR / max-abs on that sample.
+                 dense bf16 MFMA peak of 2.5 PFLOP/s (`frac`) AND against what this very device sustains on a bare,
+                 register-resident MFMA loop with random operands, measured in the same run by tools/microbench/mb_mfma
+                 (`measured_peak`, `frac_of_measured_peak`).  `traffic` comes from committed rocprofv3 PMC passes and is
+                 only quoted when they were taken with the library that is running (sha256 match).
+  cpu_baseline : the CPU oracle (oracle/mewzoom_oracle.py, torch CPU fp32 on all host cores): `value` is timed on a
+                 bounded sample of the SAME model as the GPU workload (with the GPU-vs-oracle PSNR / max-abs on that
+                 sample), `cfg1` is BASELINE.md section 3's procedure (2X-48 model, 1x3x256x256, median of >= 5).
 """
 
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -82,16 +89,45 @@ def host_cores() -> int:
     return max(1, n)
 
 
-def traffic_from_profile(args, per_gpu):
-    """HBM-side bytes per 3x3-kernel launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic_conv3x3.json:
-    FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate passes, same command with a 3-image micro-batch).
-    PMC counters cannot be collected from inside this process, so the figure is only quoted for the profiled workload."""
-    path = REPO / "profiles" / "r01_pmc_traffic_conv3x3.json"
-    if args.workload != "cfg3_1080p" or args.dtype != "bf16" or not path.exists():
+TRAFFIC_PROFILE = REPO / "profiles" / "r02_pmc_traffic_conv3x3.json"
+
+
+def library_sha256() -> str:
+    from ultrazoom_amd import _ffi
+
+    return hashlib.sha256(Path(os.environ.get("MEWZOOM_HIP_LIB", _ffi.LIB_PATH)).read_bytes()).hexdigest()
+
+
+def traffic_from_profile(args):
+    """HBM-side bytes per 3x3-kernel launch from the committed rocprofv3 PMC passes (tools/pmc_collect.sh +
+    tools/pmc_traffic.py: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate passes, the same bench.py
+    command on one 3-image micro-batch).  PMC counters cannot be collected from inside this process, so the figure is
+    quoted only for the profiled workload AND only when the profile was taken with the library that is running now
+    (sha256 recorded by pmc_traffic.py); otherwise null plus the reason."""
+    if args.workload != "cfg3_1080p" or args.dtype != "bf16":
+        return None, "no PMC profile for this workload"
+    if not TRAFFIC_PROFILE.exists():
+        return None, f"{TRAFFIC_PROFILE.name} not found"
+    try:
+        prof = json.loads(TRAFFIC_PROFILE.read_text())
+        if prof.get("library_sha256") != library_sha256():
+            return None, "stale PMC profile: it was taken with a different build of libmewzoom_hip.so"
+        return prof, None
+    except (OSError, KeyError, ValueError) as e:
+        return None, f"unreadable PMC profile: {e}"
+
+
+def measured_mfma_peak():
+    """Runs tools/microbench/mb_mfma (bare bf16 MFMA loops, random operands, >= 2 s each) as a CHILD process and returns its
+    JSON.  Must be called before this process touches the GPU (a process that has initialised HIP must not exec) and
+    never under rocprofv3 (its preloaded library initialises HIP at start-up)."""
+    exe = REPO / "tools" / "microbench" / "mb_mfma"
+    if not exe.exists() or "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ):
         return None
     try:
-        return json.loads(path.read_text())["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
+        out = subprocess.run([str(exe), "2.0"], capture_output=True, text=True, timeout=120, check=True).stdout
+        return json.loads(out.strip().splitlines()[-1])
+    except (OSError, subprocess.SubprocessError, ValueError, IndexError):
         return None
 
 
@@ -106,11 +142,11 @@ def cpu_baseline(cfg, sd, model, dtype, sample_hw):
     with torch.inference_mode():
         oracle.upscale(cfg, sd, x[:, :, : h // 2, : w // 2])  # warm-up (thread pool, allocator)
         times = []
-        for _ in range(2):
+        for _ in range(3):
             t0 = time.perf_counter()
             want = oracle.upscale(cfg, sd, x)
             times.append(time.perf_counter() - t0)
-    t = min(times)
+    t = statistics.median(times)
     r = cfg["upscale_ratio"]
     mpix = h * r * w * r / 1e6
     got = model.upscale(x.to("cuda", dtype)).float().cpu()
@@ -122,10 +158,39 @@ def cpu_baseline(cfg, sd, model, dtype, sample_hw):
         "unit": "MPix/s",
         "cores": torch.get_num_threads(),
         "kind": "port",
-        "sample": f"oracle upscale() of the same model on 1x3x{h}x{w} fp32, best of 2, {t:.2f} s/iter, "
-                  f"{oracle.flops_per_image(cfg, h, w) / t / 1e9:.0f} GFLOP/s",
+        "sample": f"oracle upscale() of the SAME model as the GPU workload on 1x3x{h}x{w} fp32, 1 warm-up + median of 3, "
+                  f"{t:.2f} s/iter, {oracle.flops_per_image(cfg, h, w) / t / 1e9:.0f} GFLOP/s "
+                  "(BASELINE.md section 3's own shape is reported under 'cfg1')",
         "gpu_vs_oracle_psnr_db": 10.0 * math.log10(1.0 / mse) if mse > 0 else float("inf"),
         "gpu_vs_oracle_max_abs": (got - want).abs().max().item(),
+        "cfg1": cpu_baseline_cfg1(cores),
+    }
+
+
+def cpu_baseline_cfg1(cores):
+    """BASELINE.md section 3 as written: the 2X model (48/96/192/384 channels, 4/4/4/8 layers), x = 1x3x256x256, fp32,
+    all host cores, >= 2 warm-ups, >= 5 iterations, median."""
+    from oracle import mewzoom_oracle as oracle  # checker / baseline only
+
+    cfg = MODELS["2x48"]
+    sd = synth_state_dict(oracle.parameter_shapes(cfg), seed=1234)
+    x = synth_image(1, 256, 256, seed=98)
+    torch.set_num_threads(cores)
+    with torch.inference_mode():
+        for _ in range(2):
+            oracle.upscale(cfg, sd, x)
+        times = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            oracle.upscale(cfg, sd, x)
+            times.append(time.perf_counter() - t0)
+    t = statistics.median(times)
+    return {
+        "value": 512 * 512 / 1e6 / t,
+        "unit": "MPix/s",
+        "cores": cores,
+        "sample": f"BASELINE configs[0]: MewZoom-2X 48ch/20L, 1x3x256x256 fp32, 2 warm-ups + median of 5, {t:.3f} s/iter, "
+                  f"{oracle.flops_per_image(cfg, 256, 256) / t / 1e9:.0f} GFLOP/s",
     }
 
 
@@ -138,6 +203,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=list(DTYPES))
     ap.add_argument("--images-in-flight", type=int, default=0, help="micro-batch inside the library (0 = default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-microbench", action="store_true", help="skip the on-box MFMA peak micro-benchmark (profiling runs)")
     ap.add_argument("--dump-launches", default="", help="write a per-launch CSV (shape, ms, TFLOP/s) of the profiled step")
     ap.add_argument("--no-gather", action="store_true", help="skip the output gather in the timed step (N > 1)")
     ap.add_argument("--images-per-gpu", type=int, default=0, help="override the workload's batch (profiling runs only)")
@@ -150,6 +216,8 @@ def main():
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         args.gpus = world
+    # the on-box MFMA peak: a child process, started BEFORE this process initialises HIP (rank 0, single-GPU runs)
+    mfma_peak = measured_mfma_peak() if (rank == 0 and world == 1 and not args.no_microbench) else None
     # one rank per GPU; MZ_BENCH_BACKEND=gloo lets several ranks share one GPU for plumbing rehearsals on a 1-GPU box
     backend = os.environ.get("MZ_BENCH_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
@@ -226,6 +294,9 @@ def main():
         engine.handle.profile_enable(False)
         conv_tflops = prof["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12 if prof["conv_ms"] > 0 else 0.0
         peak = PEAK_TFLOPS[args.dtype]
+        pmc, pmc_note = traffic_from_profile(args)
+        alg_bytes_per_launch = prof["conv_bytes"] / max(1.0, prof["conv_launches"])
+        measured_peak = mfma_peak["measured_peak_tflops"] if (mfma_peak and args.dtype != "f32") else None
         result = {
             "metric": f"upscaled MPix/sec, MewZoom-4X 1080p {args.dtype} batched inference" if args.workload.startswith("cfg3")
             else "upscaled MPix/sec",
@@ -251,12 +322,22 @@ def main():
             "whole_path_tflops_per_gpu": flops_step * args.steps / elapsed / 1e12,
             "roofline": {
                 "bound": "mfma",
-                "kernel": "3x3 implicit-GEMM convolution kernels conv3s_kernel / conv3w_kernel (all launches of one step, rank 0)",
+                "kernel": "3x3 implicit-GEMM convolution kernels (all 3x3 launches of one step, rank 0)",
                 "achieved": conv_tflops,
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": conv_tflops / peak,
-                "traffic": traffic_from_profile(args, per_gpu),
+                "measured_peak": measured_peak,
+                "frac_of_measured_peak": conv_tflops / measured_peak if measured_peak else None,
+                "measured_peak_detail": mfma_peak,
+                # HBM-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, rocprofv3 PMC passes) next to the algorithmic
+                # bytes per launch (each conv reads its input once and writes its output once, weights once)
+                "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
+                "traffic_note": pmc_note or f"{TRAFFIC_PROFILE.name}: {pmc['launches']} launches of one {pmc.get('images', 3)}-image "
+                                            "micro-batch forward, same library build (sha256 match)",
+                "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                "traffic_over_algorithmic": pmc["traffic_bytes_per_launch"] / alg_bytes_per_launch if pmc and alg_bytes_per_launch else None,
+                "traffic_bytes_per_step": pmc["traffic_bytes_per_launch"] * prof["conv_launches"] if pmc else None,
                 "launches": prof["conv_launches"],
                 "avg_launch_ms": prof["conv_ms"] / max(1.0, prof["conv_launches"]),
                 "algorithmic_tflop_per_step": prof["conv_flops"] / 1e12,

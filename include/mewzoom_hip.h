@@ -146,6 +146,11 @@ int mz_profile_dump(mz_handle* h, const char* path);
 int mz_profile_read(mz_handle* h, double* conv_ms, double* conv_flops, double* conv_launches,
                     double* other_ms, double* conv_bytes);
 
+/* Diagnostics only: copies the in-kernel cycle-stamp buffer (16 x 64 x 8 uint64) to the host.  The buffer exists only
+ * when the process was started with MZ_DEBUG_STAMPS=1 and is written only by -DMZ_STAMP builds of the kernels
+ * (tools/stamp_probe*.py); returns -1 when it does not exist.  No reference counterpart. */
+int mz_debug_read(unsigned long long* host_dst);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,15 @@ def host_cores() -> int:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Multi-process GPU tests (tests/test_sharding_gpu.py) start their rank processes from a fork server that is
+    # launched HERE, before anything in this process initialises HIP: a process that has touched the GPU must not exec
+    # another program, and a fork server forks clean children without any exec.
+    try:
+        from multiprocessing import forkserver
+
+        forkserver.ensure_running()
+    except Exception:  # noqa: BLE001
+        pass
     try:
         import torch
 

@@ -109,6 +109,30 @@ def run_model_case(ref, name, spec):
         else:
             out["sr"] = sr.numpy()
             out["up"] = up.numpy()
+        # The reference's OWN reduced-precision results (model.to(dtype) on CPU, same weights and image): the yardstick
+        # for the 16-bit GPU kernels, whose error against the fp32 result is gated relative to this one.
+        up32 = up
+        for tag, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+            low = ref.MewZoom(**config)
+            low.load_state_dict(sd)
+            low = low.to(dt).eval()
+            sr_l, qa_l = low.forward(x.to(dt))
+            up_l = low.upscale(x.to(dt))
+            sr_lf, up_lf = sr_l.float(), up_l.float()
+            out[f"ref_{tag}_err"] = np.array(
+                [
+                    (sr_lf - sr).abs().max().item(),                       # max-abs of forward() vs fp32
+                    (up_lf.double() - up32.double()).pow(2).mean().item(),  # MSE of upscale() vs fp32
+                    (qa_l.float() - qa).abs().max().item(),                # max-abs of the degradation features
+                ]
+            )
+            bits = (lambda t: t.contiguous().view(torch.int16).numpy().view(np.uint16))  # exact 16-bit patterns
+            if sample_only:
+                out[f"ref_{tag}_sr_samples"] = bits(sr_l.reshape(-1)[torch.from_numpy(idx)])
+            else:
+                out[f"ref_{tag}_sr"] = bits(sr_l)
+            out[f"ref_{tag}_qa"] = bits(qa_l)
+            del low
         if store_taps:
             # sub-modules are called through .forward exactly as the reference does
             s = model.bicubic.forward(x)
@@ -219,6 +243,7 @@ def run_checkpoint_case(ref):
     bakes from it.  Pins `bake_state_dict`."""
     config = cfg(2, (8, 16, 16, 16), (2, 2, 2, 2))
     alpha, rank = 0.75, 2
+    torch.manual_seed(1234)  # add_lora_adapters draws lora_a from the global RNG: independent of which cases ran before
     model = ref.MewZoom(**config)
     sd0 = synth_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 21)
     model.load_state_dict(sd0)

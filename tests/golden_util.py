@@ -55,6 +55,18 @@ class GoldenCase:
         return errs
 
 
+def _mse_up(self, up: torch.Tensor) -> float:
+    """MSE of a clamped result against the reference's fp32 `upscale` output (over the stored samples for sampled cases)."""
+    up = up.detach().float().cpu()
+    if self.sampled:
+        idx = torch.from_numpy(self.data["sr_idx"])
+        return (up.reshape(-1)[idx].double() - torch.from_numpy(self.data["up_samples"]).double()).pow(2).mean().item()
+    return (up.double() - torch.from_numpy(self.data["up"]).double()).pow(2).mean().item()
+
+
+GoldenCase.mse_up = _mse_up
+
+
 def psnr(a: torch.Tensor, b: torch.Tensor) -> float:
     mse = (a.double() - b.double()).pow(2).mean().item()
     return float("inf") if mse == 0 else 10.0 * np.log10(1.0 / mse)

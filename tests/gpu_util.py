@@ -9,9 +9,34 @@ import torch
 from ultrazoom_amd import _ffi
 
 DTYPES = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
-# max-abs tolerance of ONE operator on O(1) data whose inputs were already rounded to the dtype:
-# f32 = accumulation-order noise; 16-bit = one output rounding (2^-9 / 2^-11 relative) plus the same noise.
-OP_TOL = {"f32": 2e-5, "bf16": 2.5e-2, "f16": 3e-3}
+# Tolerance of ONE operator whose inputs were already rounded to the dtype and whose accumulation is fp32: the only
+# legitimate error is accumulation-order noise (f32: 2e-5 absolute on O(1) data) plus, for the 16-bit types, ONE
+# rounding of the output to the storage type: |got - want| <= 1 ulp_storage(|want|) + 1e-5, element by element.
+F32_OP_TOL = 2e-5
+MANTISSA_BITS = {"bf16": 7, "f16": 10}
+MIN_EXPONENT = {"bf16": -126, "f16": -14}
+
+
+def ulp_of(want: torch.Tensor, dt: str) -> torch.Tensor:
+    """Spacing of the storage type `dt` at |want| (element-wise, float32)."""
+    _, e = torch.frexp(want.abs().float())  # |want| = m * 2^e, m in [0.5, 1)  =>  floor(log2 |want|) = e - 1
+    e = torch.where(want == 0, torch.full_like(e, MIN_EXPONENT[dt]), e - 1).clamp(min=MIN_EXPONENT[dt])
+    return torch.ldexp(torch.ones_like(want, dtype=torch.float32), e - MANTISSA_BITS[dt])
+
+
+def op_excess(got: torch.Tensor, want: torch.Tensor, dt: str) -> float:
+    """max over elements of |got - want| / tolerance(element); <= 1 passes."""
+    diff = (got.float() - want.float()).abs()
+    if dt == "f32":
+        return (diff / F32_OP_TOL).max().item()
+    return (diff / (ulp_of(want, dt) + 1e-5)).max().item()
+
+
+def assert_op_close(got: torch.Tensor, want: torch.Tensor, dt: str, what: str = "") -> float:
+    ex = op_excess(got, want, dt)
+    worst = (got.float() - want.float()).abs().max().item()
+    assert ex <= 1.0, f"{what} {dt}: |got - want| reaches {ex:.2f} x (1 ulp + 1e-5) (max-abs {worst:.3e})"
+    return worst
 
 
 def pad16(c: int) -> int:

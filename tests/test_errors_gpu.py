@@ -8,7 +8,7 @@ import torch
 import torch.nn.functional as F
 
 from golden_util import GoldenCase
-from gpu_util import DTYPES, OP_TOL, alloc_act, from_act, op_conv, q, to_act
+from gpu_util import DTYPES, assert_op_close, alloc_act, from_act, op_conv, q, to_act
 from ultrazoom_amd import MewZoom, _ffi
 from ultrazoom_amd.synth import hash_uniform
 
@@ -63,7 +63,6 @@ def test_conv3x3_fuzz(dt):
         want = F.conv2d(x, w, padding=1)
         if silu:
             want = F.silu(want)
-        err = (from_act(out, cout) - want).abs().max().item()
-        assert err < OP_TOL[dt], f"case {i}: B={B} H={H} W={W} cin={cin} cout={cout} silu={silu}: max-abs {err}"
+        err = assert_op_close(from_act(out, cout), want, dt, f"case {i}: B={B} H={H} W={W} cin={cin} cout={cout} silu={silu}")
         worst = max(worst, err)
     print(f"conv3x3 fuzz {dt}: worst max-abs {worst:.3e}")

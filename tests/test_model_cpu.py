@@ -100,3 +100,69 @@ def test_bake_reference_checkpoint_weight_norm_and_lora():
     # a wrong alpha must not pass silently
     off = bake_state_dict(raw, lora_alpha=alpha * 2)
     assert any((off[k] - want[k]).abs().max().item() > 1e-3 for k in want if k.endswith("conv.weight"))
+
+
+def _g10():
+    import numpy as np
+
+    d = np.load(GOLDEN / "g10_checkpoint.npz")
+    raw = {k[len("raw/"):]: torch.from_numpy(d[k]) for k in d.files if k.startswith("raw/")}
+    want = {k[len("baked/"):]: torch.from_numpy(d[k]) for k in d.files if k.startswith("baked/")}
+    return json.loads(str(d["config_json"])), raw, want, int(d["lora_rank"]), float(d["lora_alpha"])
+
+
+def test_reference_checkpoint_recipe_runs_unchanged():
+    """The statements of the reference's own loader (test_compare.py:32-45, validate.py:57-67) against the drop-in class:
+    add_weight_norms() [+ add_lora_adapters()] -> strip `_orig_mod.` -> load_state_dict() -> remove_parameterizations()."""
+    cfg, raw, want, rank, alpha = _g10()
+    model = MewZoom(**cfg)
+    model.add_weight_norms()
+    model.add_lora_adapters(rank, alpha)
+    state_dict = dict(raw)
+    # Compensate for compiled state dict.  (test_compare.py:39-41)
+    for key in list(state_dict.keys()):
+        state_dict[key.replace("_orig_mod.", "")] = state_dict.pop(key)
+    model.load_state_dict(state_dict)
+    model.remove_parameterizations()
+    model.eval()
+    assert set(model.state_dict()) == set(want)
+    for k, v in model.state_dict().items():
+        assert torch.allclose(v, want[k], atol=2e-7, rtol=1e-6), k
+    # LoRA tensors without add_lora_adapters(): the reference rejects the unexpected keys; so does this class
+    with pytest.raises(RuntimeError, match="add_lora_adapters"):
+        m2 = MewZoom(**cfg)
+        m2.add_weight_norms()
+        m2.load_state_dict(state_dict)
+    # interface completeness (model.py:104-147)
+    model.enable_activation_checkpointing()
+    before = model.stem.conv.weight.clone()
+    model.initialize_weights()
+    assert not torch.equal(before, model.stem.conv.weight)
+    with pytest.raises(AssertionError):
+        model.add_lora_adapters(0, 1.0)
+
+
+def test_module_copies_and_pickles():
+    import copy
+    import io
+    import pickle
+
+    from ultrazoom_amd import _ffi
+
+    case = GoldenCase("g1_2x_c16")
+    m = MewZoom(**case.config)
+    m.load_state_dict(case.weights())
+    for clone in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+        assert clone._engine is None
+        for (k1, v1), (k2, v2) in zip(m.state_dict().items(), clone.state_dict().items()):
+            assert k1 == k2 and torch.equal(v1, v2)
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    # the raw handle itself must refuse to be copied (two owners of one mz_handle would free it twice)
+    h = _ffi.Handle(case.config, _ffi.MZ_F32)
+    with pytest.raises(TypeError):
+        copy.deepcopy(h)
+    with pytest.raises(TypeError):
+        pickle.dumps(h)
+    h.close()
+    m.refresh_weights()  # a no-op without an engine

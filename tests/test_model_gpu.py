@@ -2,10 +2,15 @@
 
 Gates
   float32 : max-abs <= 1e-3 against the reference's own outputs (the golden fixtures) — the bar
-            BASELINE.json's north_star states; the f32 MFMA path lands around 1e-5.
-  bf16/f16: reduced-precision storage cannot meet 1e-3 through 20-40 layers (the reference's own bf16
-            differs from its fp32 by 7e-3 max-abs / 56.6 dB), so these are gated on
-            PSNR (data range 1.0, as pretrain.py:209) and a looser max-abs, both written below.
+            BASELINE.json's north_star states; the f32 MFMA path lands around 1e-6.
+  bf16/f16: reduced-precision storage cannot meet 1e-3 through 20-40 layers, so the yardstick is the REFERENCE'S OWN
+            reduced-precision error: every golden fixture also holds the outputs of the reference run with
+            `model.to(bfloat16 / float16)` on the CPU (make_golden.py) and its error against its own fp32 result.
+            The GPU kernels' error against the fp32 fixture must be <= LOWP_RATIO x that error, in max-abs, in MSE
+            (= PSNR, data range 1.0 as pretrain.py:209) and on the degradation features.
+            Where no fixture exists (configurations only the oracle covers, full BASELINE sizes) the yardstick is the
+            oracle's rounding-matched mode (`storage=dtype`: fp32 arithmetic, every tensor the GPU path keeps in HBM
+            rounded where the GPU rounds it), whose own error tests/test_oracle_golden.py ties to the reference's.
 """
 
 import os
@@ -22,11 +27,29 @@ from ultrazoom_amd.synth import synth_image, synth_state_dict
 pytestmark = pytest.mark.gpu
 
 F32_TOL = 1e-3
-# measured on MI355X: bf16 5.6e-3 .. 8.9e-3 max-abs / 56.7 .. 59.0 dB; fp16 7.0e-4 .. 1.2e-3 / 74.8 .. 76.6 dB
-LOWP = {
-    torch.bfloat16: dict(max_abs=0.03, psnr=52.0, qa=0.01),
-    torch.float16: dict(max_abs=4e-3, psnr=70.0, qa=1e-3),
-}
+LOWP_RATIO = 1.25      # allowed GPU error / the reference's own reduced-precision error (max-abs and RMS alike)
+MATCHED_MAX_RATIO = 1.5  # max-abs against the rounding-matched oracle's error: the maximum of a different rounding
+                         # realisation over ~1e5 samples is noisier than an RMS, hence the wider factor there
+TAG = {torch.bfloat16: "bf16", torch.float16: "f16"}
+HALF_ULP_AT_1 = {torch.bfloat16: 2.0 ** -9, torch.float16: 2.0 ** -12}  # qa is O(0.1): its own final rounding
+
+
+def lowp_gate_vs_matched(got: torch.Tensor, want32: torch.Tensor, matched: torch.Tensor, what: str):
+    """`got` (GPU, 16-bit) against the fp32 oracle `want32`, relative to the rounding-matched oracle's own error."""
+    got, want32, matched = got.float().cpu(), want32.float(), matched.float()
+    e_got, e_ref = (got - want32).abs().max().item(), (matched - want32).abs().max().item()
+    m_got, m_ref = (got - want32).double().pow(2).mean().item(), (matched - want32).double().pow(2).mean().item()
+    same = (got == matched).float().mean().item()
+    print(f"{what}: max-abs {e_got:.3e} (matched oracle {e_ref:.3e}), PSNR {psnr_of(m_got):.1f} dB (matched {psnr_of(m_ref):.1f}), "
+          f"{100 * same:.1f} % of the elements equal the matched oracle bit for bit")
+    assert e_got <= MATCHED_MAX_RATIO * e_ref, (what, e_got, e_ref)
+    assert m_got <= LOWP_RATIO ** 2 * m_ref, (what, psnr_of(m_got), psnr_of(m_ref))
+
+
+def psnr_of(mse: float) -> float:
+    import math
+
+    return float("inf") if mse <= 0 else 10.0 * math.log10(1.0 / mse)
 
 
 def build(case_or_cfg, weights, dtype):
@@ -54,20 +77,24 @@ def test_golden_f32(name):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("name", MODEL_CASES)
 def test_golden_low_precision(name, dtype):
+    """16-bit kernels (the ones the benchmark runs) against the reference's fp32 fixture, gated by the reference's OWN
+    bf16 / fp16 error on the same weights and image (stored in the fixture)."""
     case = GoldenCase(name)
-    gate = LOWP[dtype]
+    tag = TAG[dtype]
+    ref_max, ref_mse, ref_qa = (float(v) for v in case.data[f"ref_{tag}_err"])
     m = build(case, case.weights(), dtype)
     x = case.image().to("cuda", dtype)
-    with torch.inference_mode():
-        want_sr, want_qa = oracle.forward(case.config, case.weights(), case.image())
     sr, qa = m.forward(x)
     up = m.upscale(x)
     assert sr.dtype == dtype and up.dtype == dtype and qa.dtype == dtype
-    err = (sr.float().cpu() - want_sr).abs().max().item()
-    p = psnr(up.float().cpu(), want_sr.clamp(0, 1))
-    qa_err = (qa.float().cpu() - want_qa).abs().max().item()
-    print(f"{name}: {dtype} max-abs {err:.3e} PSNR {p:.1f} dB qa {qa_err:.3e}")
-    assert err <= gate["max_abs"] and p >= gate["psnr"] and qa_err <= gate["qa"]
+    errs = case.compare_sr(sr, up)
+    mse = case.mse_up(up)
+    qa_err = (qa.float().cpu() - torch.from_numpy(case.data["qa"])).abs().max().item()
+    print(f"{name}: {tag} max-abs {errs['sr']:.3e} (reference's own {ref_max:.3e}), PSNR {psnr_of(mse):.1f} dB "
+          f"(reference's own {psnr_of(ref_mse):.1f}), qa {qa_err:.3e} (reference's own {ref_qa:.3e})")
+    assert errs["sr"] <= LOWP_RATIO * ref_max
+    assert mse <= LOWP_RATIO ** 2 * ref_mse
+    assert qa_err <= LOWP_RATIO * ref_qa + HALF_ULP_AT_1[dtype]
 
 
 def test_batch_independence_and_micro_batching():
@@ -105,11 +132,13 @@ def test_cfg2_full_size_540p_against_oracle():
     err = (got - want).abs().max().item()
     print(f"cfg2 540p f32: max-abs {err:.3e}")
     assert err <= F32_TOL
+    del m
+    torch.cuda.empty_cache()
+    with torch.inference_mode():
+        matched = oracle.upscale(CFG2, sd, x, storage=torch.bfloat16)
     mb = build(CFG2, sd, torch.bfloat16)
-    gb = mb.upscale(x.to("cuda", torch.bfloat16)).float().cpu()
-    p = psnr(gb, want)
-    print(f"cfg2 540p bf16: max-abs {(gb - want).abs().max().item():.3e} PSNR {p:.1f} dB")
-    assert p >= 40.0
+    gb = mb.upscale(x.to("cuda", torch.bfloat16))
+    lowp_gate_vs_matched(gb, want, matched, "cfg2 540p bf16")
 
 
 def test_cfg3_model_reduced_size_against_oracle_and_full_size_properties():
@@ -126,10 +155,10 @@ def test_cfg3_model_reduced_size_against_oracle_and_full_size_properties():
     assert err <= F32_TOL
     del m
     torch.cuda.empty_cache()
+    with torch.inference_mode():
+        matched = oracle.upscale(CFG3, sd, x, storage=torch.bfloat16)
     mb = build(CFG3, sd, torch.bfloat16)
-    p = psnr(mb.upscale(x.to("cuda", torch.bfloat16)).float().cpu(), want)
-    print(f"cfg3 model 136x240 bf16: PSNR {p:.1f} dB")
-    assert p >= 40.0
+    lowp_gate_vs_matched(mb.upscale(x.to("cuda", torch.bfloat16)), want, matched, "cfg3 model 136x240 bf16")
     # full 1080p -> 8K: two different images; each must equal its own single-image run, bit for bit,
     # and the clamp must hold everywhere
     xb = synth_image(2, 1080, 1920, 33).to("cuda", torch.bfloat16)
@@ -143,6 +172,57 @@ def test_cfg3_model_reduced_size_against_oracle_and_full_size_properties():
     ref_bic = oracle.bicubic_upsample(xb[0:1, :, :64, :64].float().cpu(), 4).clamp(0, 1)
     got = both[0:1, :, : 64 * 4 - 16, : 64 * 4 - 16].float().cpu()
     assert (got - ref_bic[..., : 64 * 4 - 16, : 64 * 4 - 16]).abs().mean().item() < 0.2
+
+
+def _corner_crop(H, W, ch, cw):
+    """Bottom-right crop origin: a multiple of 8 (the down-sampling pyramid then lines up with the full image's)."""
+    y0, x0 = H - ch, W - cw
+    assert y0 % 8 == 0 and x0 % 8 == 0 and y0 >= 0 and x0 >= 0
+    return y0, x0
+
+
+def test_cfg3_full_size_1080p_bottom_right_corner_against_oracle():
+    """The BENCHMARKED workload's geometry (434 M-parameter 4X model, 1080x1920 images, micro-batches of 3): oracle
+    parity where addressing errors would show -- the LAST image of a 3-image micro-batch, bottom-right corner, i.e. the
+    largest offsets of every tensor (2160x3840x192-channel head tensors included).  The oracle runs on a crop whose
+    origin is a multiple of 8 and whose cut edges are >= receptive_field() away from the compared region (the exact-tiling
+    property, tests/test_tiling.py); the bottom and right edges are the image's own.  f32 is held to the 1e-3 bar, bf16
+    (the benchmarked kernels) to the rounding-matched oracle."""
+    from ultrazoom_amd.tiling import receptive_field
+
+    H, W, ch, cw = 1080, 1920, 536, 608
+    rf = receptive_field(CFG3)
+    y0, x0 = _corner_crop(H, W, ch, cw)
+    keep_h, keep_w = ch - rf, cw - rf
+    assert keep_h >= 96 and keep_w >= 96
+    sd = synth_state_dict(oracle.parameter_shapes(CFG3), 31)
+    x = synth_image(3, H, W, 35)
+    crop = x[2:3, :, y0:, x0:]
+    torch.set_num_threads(host_cores())
+    with torch.inference_mode():
+        want = oracle.upscale(CFG3, sd, crop)[:, :, 4 * rf :, 4 * rf :]
+        matched = oracle.upscale(CFG3, sd, crop, storage=torch.bfloat16)[:, :, 4 * rf :, 4 * rf :]
+    m = build(CFG3, sd, torch.float32)
+    m.max_images_in_flight = 3
+    full = m.upscale(x.cuda())
+    assert full.shape == (3, 3, 4 * H, 4 * W)
+    got = full[2:3, :, 4 * (y0 + rf) :, 4 * (x0 + rf) :].cpu()
+    err = (got - want).abs().max().item()
+    print(f"cfg3 1080p f32, image 2 of a 3-image micro-batch, bottom-right {4 * keep_h}x{4 * keep_w} output pixels: max-abs {err:.3e}")
+    assert err <= F32_TOL
+    del m, full
+    torch.cuda.empty_cache()
+    mb = build(CFG3, sd, torch.bfloat16)
+    mb.max_images_in_flight = 3
+    fullb = mb.upscale(x.to("cuda", torch.bfloat16))
+    assert fullb.min().item() >= 0.0 and fullb.max().item() <= 1.0
+    lowp_gate_vs_matched(fullb[2:3, :, 4 * (y0 + rf) :, 4 * (x0 + rf) :], want, matched, "cfg3 1080p bf16 bottom-right corner")
+    # and the top-left corner of image 1 (the crop's cut edges are now bottom / right)
+    with torch.inference_mode():
+        crop1 = x[1:2, :, :ch, :cw]
+        want1 = oracle.upscale(CFG3, sd, crop1)[:, :, : 4 * keep_h, : 4 * keep_w]
+        matched1 = oracle.upscale(CFG3, sd, crop1, storage=torch.bfloat16)[:, :, : 4 * keep_h, : 4 * keep_w]
+    lowp_gate_vs_matched(fullb[1:2, :, : 4 * keep_h, : 4 * keep_w], want1, matched1, "cfg3 1080p bf16 top-left corner of image 1")
 
 
 def test_cfg5_substitute_4k_single_image_fp16():
@@ -161,11 +241,16 @@ def test_cfg5_substitute_4k_single_image_fp16():
     full = m.upscale(x.to("cuda", torch.float16))
     assert full.shape == (1, 3, 4320, 7680)
     assert full.min().item() >= 0.0 and full.max().item() <= 1.0
-    got = full[:, :, : 2 * (ch - margin), : 2 * (cw - margin)].float().cpu()
-    p = psnr(got, want)
-    err = (got - want).abs().max().item()
-    print(f"cfg5-substitute 4K fp16: max-abs {err:.3e} PSNR {p:.1f} dB (crop check)")
-    assert p >= 70.0 and err <= 4e-3
+    with torch.inference_mode():
+        matched = oracle.upscale(CFG2, sd, x[:, :, :ch, :cw], storage=torch.float16)[:, :, : 2 * (ch - margin), : 2 * (cw - margin)]
+    lowp_gate_vs_matched(full[:, :, : 2 * (ch - margin), : 2 * (cw - margin)], want, matched, "cfg5-substitute 4K fp16 top-left")
+    # bottom-right corner: the largest offsets of every tensor (crop origin = 0 mod 8; the cut edges are top / left)
+    y0, x0 = _corner_crop(2160, 3840, ch, cw)
+    with torch.inference_mode():
+        crop = x[:, :, y0:, x0:]
+        want_br = oracle.upscale(CFG2, sd, crop)[:, :, 2 * margin :, 2 * margin :]
+        matched_br = oracle.upscale(CFG2, sd, crop, storage=torch.float16)[:, :, 2 * margin :, 2 * margin :]
+    lowp_gate_vs_matched(full[:, :, 2 * (y0 + margin) :, 2 * (x0 + margin) :], want_br, matched_br, "cfg5-substitute 4K fp16 bottom-right")
     assert torch.equal(m.upscale(x.to("cuda", torch.float16)), full)
 
 
@@ -221,16 +306,15 @@ def test_mixed_channel_configs_against_oracle(spec, dtype):
     with torch.inference_mode():
         want_sr, want_qa = oracle.forward(cfg, sd, x)
         sr, qa = m.forward(x.to("cuda", dtype))
-    sr = sr.float().cpu()
-    err = (sr - want_sr).abs().max().item()
+    err = (sr.float().cpu() - want_sr).abs().max().item()
     qa_err = (qa.float().cpu() - want_qa).abs().max().item()
     if dtype == torch.float32:
         assert err <= F32_TOL and qa_err <= F32_TOL, (err, qa_err)
     else:
-        gate = LOWP[dtype]
-        p = psnr(sr.clamp(0, 1), want_sr.clamp(0, 1))
-        print(f"{spec} {dtype}: max-abs {err:.3e} psnr {p:.1f} dB qa {qa_err:.3e}")
-        assert err <= gate["max_abs"] and p >= gate["psnr"] and qa_err <= gate["qa"], (err, p, qa_err)
+        with torch.inference_mode():
+            m_sr, m_qa = oracle.forward(cfg, sd, x, storage=dtype)
+        lowp_gate_vs_matched(sr, want_sr, m_sr, f"{spec} {TAG[dtype]}")
+        assert qa_err <= MATCHED_MAX_RATIO * (m_qa - want_qa).abs().max().item() + HALF_ULP_AT_1[dtype], qa_err
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -251,9 +335,13 @@ def test_kernel_variants_agree(dtype, monkeypatch):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
+        m.refresh_weights()  # the knobs are read when the library handle is created
         outs[name] = m.upscale(xg).float().cpu()
-    gate = LOWP[dtype]
+    with torch.inference_mode():
+        matched = oracle.upscale(case.config, sd, x, storage=dtype)
+    e_ref = (matched - want).abs().max().item()
     for name, y in outs.items():
-        err = (y - want).abs().max().item()
-        assert err <= gate["max_abs"] and psnr(y, want) >= gate["psnr"], (name, err)
-        assert (y - outs["default"]).abs().max().item() <= gate["max_abs"], name
+        lowp_gate_vs_matched(y, want, matched, f"variant {name} {TAG[dtype]}")
+        # two variants are two rounding realisations of the same arithmetic: they differ by no more than each
+        # differs from the fp32 result
+        assert (y - outs["default"]).abs().max().item() <= 2 * MATCHED_MAX_RATIO * e_ref, name

@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from gpu_util import DTYPES, OP_TOL, alloc_act, from_act, op_conv, pad16, pad_part, q, stream_ptr, to_act
+from gpu_util import DTYPES, assert_op_close, alloc_act, from_act, op_conv, pad16, pad_part, q, stream_ptr, to_act
 from oracle import mewzoom_oracle as oracle
 from ultrazoom_amd import _ffi
 from ultrazoom_amd.synth import hash_uniform
@@ -54,8 +54,7 @@ def test_conv3x3(dt, case):
     if silu:
         want = F.silu(want)
     got = from_act(out, cout)
-    err = (got - want).abs().max().item()
-    assert err < OP_TOL[dt], f"max-abs {err}"
+    assert_op_close(got, want, dt)
     if pad16(cout) > cout:
         assert pad_part(out, cout).abs().max().item() == 0.0, "pad channels must be written as zeros"
 
@@ -96,8 +95,7 @@ def test_conv3x3_persistent(dt, case, monkeypatch):
     if silu:
         want = F.silu(want)
     for o in outs:
-        err = (from_act(o, cout) - want).abs().max().item()
-        assert err < OP_TOL[dt], f"max-abs {err}"
+        assert_op_close(from_act(o, cout), want, dt)
     assert torch.equal(outs[0], outs[1]), "the result must not depend on the number of persistent workgroups"
     assert torch.equal(outs[2], outs[3]), "persistent and per-tile 32x32 kernels must agree bit for bit"
     if dt == "f32":
@@ -115,8 +113,7 @@ def test_subpixel_conv_persistent(dt, monkeypatch):
     out = alloc_act(B, cq, Hout, Wout, dtype)
     op_conv(dtype, 1, to_act(x, dtype), None, w, 0.0, out, B, H, W, cin, cout, Hout, Wout)
     want = oracle.fit_to(oracle.subpixel_conv(x, w), (Hout, Wout))
-    err = (from_act(out, cq) - want).abs().max().item()
-    assert err < OP_TOL[dt], f"max-abs {err}"
+    assert_op_close(from_act(out, cq), want, dt)
 
 
 D2S_CASES = [
@@ -140,8 +137,7 @@ def test_subpixel_conv(dt, case):
     op_conv(dtype, 1, to_act(x, dtype), None, w, 0.0, out, B, H, W, cin, cout, Hout, Wout)
     want = oracle.fit_to(oracle.subpixel_conv(x, w), (Hout, Wout))
     got = from_act(out, cq)
-    err = (got - want).abs().max().item()
-    assert err < OP_TOL[dt], f"max-abs {err}"
+    assert_op_close(got, want, dt)
     if pad16(cq) > cq:
         assert pad_part(out, cq).abs().max().item() == 0.0
 
@@ -159,8 +155,7 @@ def test_pixel_crush(dt, case):
     out = alloc_act(B, cout, H // 2, W // 2, dtype)
     op_conv(dtype, 2, to_act(x, dtype), None, w, 0.0, out, B, H, W, cin, cout)
     want = F.conv2d(x, w, stride=2)
-    err = (from_act(out, cout) - want).abs().max().item()
-    assert err < OP_TOL[dt], f"max-abs {err}"
+    assert_op_close(from_act(out, cout), want, dt)
 
 
 MIX_CASES = [(2, 7, 9, 16), (1, 16, 17, 24), (1, 20, 33, 48), (2, 8, 40, 96), (1, 5, 13, 128), (1, 3, 50, 384),
@@ -180,8 +175,7 @@ def test_adaptive_residual_mix(dt, case):
     out = alloc_act(B, c, H, W, dtype)
     op_conv(dtype, 3, to_act(x, dtype), to_act(z, dtype), w, alpha, out, B, H, W, 2 * c, c)
     want = oracle.residual_mix(x, z, w, torch.tensor(alpha))
-    err = (from_act(out, c) - want).abs().max().item()
-    assert err < OP_TOL[dt], f"max-abs {err}"
+    assert_op_close(from_act(out, c), want, dt)
     if pad16(c) > c:
         assert pad_part(out, c).abs().max().item() == 0.0
 
@@ -201,8 +195,7 @@ def test_stem(dt, case):
         ctypes.c_void_p(bd.data_ptr()), ctypes.c_void_p(out.data_ptr()), B, H, W, c, ctypes.c_void_p(stream_ptr())))
     torch.cuda.synchronize()
     want = F.conv2d(x, w, b)
-    err = (from_act(out, c) - want).abs().max().item()
-    assert err < OP_TOL[dt], f"max-abs {err}"
+    assert_op_close(from_act(out, c), want, dt)
     if pad16(c) > c:
         assert pad_part(out, c).abs().max().item() == 0.0
 
@@ -237,5 +230,4 @@ def test_final_subpixel_bicubic_add_clamp(dt, case):
     want = oracle.bicubic_upsample(img, R) + oracle.subpixel_conv(feat, w)
     if clamp:
         want = want.clamp(0, 1)
-    err = (out.float().cpu() - want).abs().max().item()
-    assert err < OP_TOL[dt], f"max-abs {err}"
+    assert_op_close(out.float().cpu(), want, dt)

@@ -39,6 +39,31 @@ def test_model_case(name):
             assert np.abs(got - case.data[key]).max() < TOL, key
 
 
+@pytest.mark.parametrize("tag,dtype", [("bf16", torch.bfloat16), ("f16", torch.float16)])
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_rounding_matched_mode_is_no_worse_than_the_reference_in_reduced_precision(name, tag, dtype):
+    """The oracle's `storage=dtype` mode (fp32 arithmetic, tensors rounded where the GPU path rounds them) is the
+    yardstick of the 16-bit GPU tests wherever no fixture exists.  Tie it to the reference: against the reference's fp32
+    outputs it must err no more than the reference's OWN bf16 / fp16 run does (stored in the fixture), and it must
+    stay within a small factor of it, so that it is neither a loose nor an arbitrary bar."""
+    case = GoldenCase(name)
+    ref_max, ref_mse, ref_qa = (float(v) for v in case.data[f"ref_{tag}_err"])
+    with torch.inference_mode():
+        sr, qa = oracle.forward(case.config, case.weights(), case.image(), storage=dtype)
+    errs = case.compare_sr(sr, sr.clamp(0, 1))
+    mse = case.mse_up(sr.clamp(0, 1))
+    qa_err = np.abs(qa.numpy() - case.data["qa"]).max()
+    assert errs["sr"] <= ref_max and mse <= ref_mse, (errs, ref_max, mse, ref_mse)
+    assert errs["sr"] >= 0.2 * ref_max and mse >= 0.1 * ref_mse, "the matched mode must carry real rounding error"
+    assert qa_err <= ref_qa + (2.0 ** -9 if tag == "bf16" else 2.0 ** -12)
+    # the stored 16-bit outputs of the reference decode to the stored error figures
+    key = f"ref_{tag}_sr_samples" if case.sampled else f"ref_{tag}_sr"
+    low = torch.from_numpy(case.data[key].view(np.int16).copy()).view(dtype).float()
+    want = torch.from_numpy(case.data["sr_samples"] if case.sampled else case.data["sr"])
+    got_max = (low.reshape(-1) - want.reshape(-1)).abs().max().item()
+    assert got_max <= ref_max + 1e-9 and (case.sampled or abs(got_max - ref_max) < 1e-9)
+
+
 def test_ops():
     g = np.load(GOLDEN / "g6_ops.npz")
     x = synth_image(1, 9, 11, 21)

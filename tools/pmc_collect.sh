@@ -1,13 +1,14 @@
 #!/bin/bash
 # Collects rocprofv3 evidence for one small forward (3 images = one micro-batch of the cfg3 workload) — run on the GPU box.
-# usage: tools_pmc.sh <outdir-under-gpurun_out>      (separate passes: counters never share a run with other traces)
+# usage: tools/pmc_collect.sh <outdir-under-gpurun_out> [workload]   (separate passes: counters never share a run with other traces)
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/${1:-pmc}
+WL=${2:-cfg3_1080p}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --images-per-gpu 3"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/stats.log 2>&1
+CMD="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-microbench --images-per-gpu 3 --workload $WL"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-microbench --workload $WL > $OUT/stats.log 2>&1
 echo "stats rc=$?"
 run() { # name counters...
   local name=$1; shift

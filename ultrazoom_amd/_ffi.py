@@ -124,6 +124,16 @@ class Handle:
 
     __del__ = close
 
+    # A handle owns device memory through a raw pointer: copying the Python object would free it twice.
+    def __copy__(self):
+        raise TypeError("an mz_handle cannot be copied; build a new Handle")
+
+    def __deepcopy__(self, memo):
+        raise TypeError("an mz_handle cannot be copied; build a new Handle")
+
+    def __reduce__(self):
+        raise TypeError("an mz_handle cannot be pickled; build a new Handle")
+
     @property
     def ptr(self):
         return self._h

@@ -10,3 +10,7 @@ mkdir -p "$here/build"
 wait
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC "$here/build/mz_kernels.o" "$here/build/mz_host.o" -o "$out"
 echo "built $out"
+# on-box MFMA peak micro-benchmark (bench.py's `roofline.measured_peak` leg)
+mb="$here/../../tools/microbench"
+"$HIPCC" --offload-arch=gfx950 -O3 "$mb/mb_mfma.hip" -o "$mb/mb_mfma"
+echo "built $mb/mb_mfma"

@@ -37,15 +37,47 @@ static int fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(MZ_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+// Per-device state: the raised dynamic-LDS limits (hipFuncSetAttribute applies to the CURRENT device) and the CU count.
+static constexpr int kMaxDevices = 64;
+static int g_dev_ready[kMaxDevices];  // 0 unknown, 1 ok
+static int g_dev_cus[kMaxDevices];
+
 static int ensure_device_ready() {
-    static int state = 0;  // 0 unknown, 1 ok, -1 failed
-    if (state == 1) return MZ_OK;
-    int n = 0;
+    int n = 0, dev = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(MZ_ERR_NO_DEVICE, "no HIP device visible");
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return fail(MZ_ERR_NO_DEVICE, "bad current device");
+    if (g_dev_ready[dev] == 1) return MZ_OK;
     hipError_t e = init_kernels();
     if (e != hipSuccess) return fail(MZ_ERR_HIP, "kernel init failed: %s", hipGetErrorString(e));
-    state = 1;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    g_dev_cus[dev] = cus / 8 * 8;
+    g_dev_ready[dev] = 1;
     return MZ_OK;
+}
+
+// Environment knobs (A/B timing and test coverage of every kernel variant).  Read ONCE, when a
+// handle is created (or per mz_op_* call), never on the launch path.
+struct Knobs {
+    int use_glds = 1;       // MZ_USE_GLDS=0: stage through registers instead of LDS-DMA (needs a -DMZ_REG_STAGING build)
+    bool wide = true;       // MZ_NO_WIDE=1: force the 256-pixel kernel
+    bool fuse = true;       // MZ_NO_FUSE=1: conv2 and the mix as two launches
+    bool s16 = true;        // MZ_NO_S16=1: keep 16-bit types on the 32x32x16 kernels
+    bool fuse16 = true;     // MZ_NO_FUSE16=1: the fused mix stays on the 32x32x16 kernel
+    bool mix16 = true;      // MZ_NO_MIX16=1: C = k * 192 mixes on the general 1x1 kernel
+    int persist = -1;       // MZ_NO_PERSIST=1 -> 0 (one workgroup per tile); MZ_PERSIST_WGS=n -> n; -1 = one per CU
+};
+static Knobs read_knobs() {
+    Knobs k;
+    if (const char* e = getenv("MZ_USE_GLDS")) k.use_glds = atoi(e) != 0;
+    k.wide = getenv("MZ_NO_WIDE") == nullptr;
+    k.fuse = getenv("MZ_NO_FUSE") == nullptr;
+    k.s16 = getenv("MZ_NO_S16") == nullptr;
+    k.fuse16 = getenv("MZ_NO_FUSE16") == nullptr;
+    k.mix16 = getenv("MZ_NO_MIX16") == nullptr;
+    if (getenv("MZ_NO_PERSIST") != nullptr) k.persist = 0;
+    else if (const char* e = getenv("MZ_PERSIST_WGS")) { const int n = atoi(e) / 8 * 8; k.persist = n > 0 ? n : 0; }
+    return k;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -160,7 +192,7 @@ struct mz_handle {
     std::vector<Slot> slots;
     std::unordered_map<std::string, int> slot_index;
     bool device_ready = false;
-    int use_glds = 1;
+    Knobs knobs;
     // profiling
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -248,7 +280,7 @@ extern "C" int mz_create(const mz_config* cfg, int dtype, mz_handle** out) {
         h->dec[i] = ly[i] / 2;        // floor, model.py:290-300
     }
     h->nhead = cfg->upscale_ratio == 2 ? 1 : (cfg->upscale_ratio == 4 ? 2 : 3);  // model.py:945
-    if (const char* e = getenv("MZ_USE_GLDS")) h->use_glds = atoi(e) != 0;
+    h->knobs = read_knobs();
 
     // Registry in the reference's state_dict order.
     h->slots.reserve(1024);
@@ -340,15 +372,17 @@ extern "C" int mz_weight_info(const mz_handle* h, int index, const char** name, 
     return s.ndim;
 }
 
-static int prepare_device(mz_handle* h) {
+static int prepare_device(mz_handle* h, hipStream_t st) {
     if (h->device_ready) return MZ_OK;
     int rc = ensure_device_ready();
     if (rc) return rc;
+    // zero fills go to the CALLER's stream, like every later use of these buffers (a blocking memset on the NULL stream
+    // is not ordered with work on a non-blocking stream)
     HIPCHK(hipMalloc(&h->zero_page, 4096));
-    HIPCHK(hipMemset(h->zero_page, 0, 4096));
+    HIPCHK(hipMemsetAsync(h->zero_page, 0, 4096, st));
     const int cp0 = pad16(h->ch[0]);
     HIPCHK(hipMalloc((void**)&h->stem_w4, sizeof(float) * 4 * cp0));
-    HIPCHK(hipMemset(h->stem_w4, 0, sizeof(float) * 4 * cp0));
+    HIPCHK(hipMemsetAsync(h->stem_w4, 0, sizeof(float) * 4 * cp0, st));
     HIPCHK(hipMalloc((void**)&h->qa_bias, sizeof(float) * std::max(1, h->cfg.num_deg_features)));
     h->device_ready = true;
     return MZ_OK;
@@ -384,9 +418,9 @@ extern "C" int mz_set_weight(mz_handle* h, const char* name, const float* dev_f3
     for (int i = 0; i < ndim; ++i)
         if (shape[i] != s.shape[i])
             return fail(MZ_ERR_SHAPE_MISMATCH, "'%s': dim %d is %lld, expected %lld", name, i, (long long)shape[i], (long long)s.shape[i]);
-    int rc = prepare_device(h);
-    if (rc) return rc;
     hipStream_t st = (hipStream_t)hip_stream;
+    int rc = prepare_device(h, st);
+    if (rc) return rc;
     switch (s.kind) {
         case SK_CONV: {
             int rc2 = pack_conv(*s.conv, h->dtype, dev_f32, st);
@@ -522,24 +556,14 @@ extern "C" int mz_debug_read(unsigned long long* host_dst) {
     return hipMemcpy(host_dst, b, 16 * 64 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -6;
 }
 
-// workgroups of a persistent launch: one per CU, a multiple of 8 (one equal share per XCD).
-// MZ_NO_PERSIST=1: one workgroup per tile everywhere (A/B timing); MZ_PERSIST_WGS=n: force n (tests use 8 / 16 so that
+// workgroups of a persistent launch: one per CU of the CURRENT device, a multiple of 8 (one equal share per XCD).
+// Knobs::persist overrides: 0 = one workgroup per tile everywhere (A/B timing); n = force n (tests use 8 / 16 so that
 // small images walk several tiles per workgroup).
-static int persistent_workgroups() {
-    if (getenv("MZ_NO_PERSIST") != nullptr) return 0;
-    if (const char* e = getenv("MZ_PERSIST_WGS")) {
-        const int n = atoi(e) / 8 * 8;
-        return n > 0 ? n : 0;
-    }
-    static int cus = -1;
-    if (cus < 0) {
-        int dev = 0, n = 0;
-        cus = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
-            cus = n / 8 * 8;
-    }
-    return cus;
+static int persistent_workgroups(const Knobs& k) {
+    if (k.persist >= 0) return k.persist;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 0;
+    return g_dev_cus[dev];
 }
 
 struct Runner {
@@ -547,11 +571,12 @@ struct Runner {
     hipStream_t s;
     int dtype;
     int rc = MZ_OK;
-    bool wide_tiles = getenv("MZ_NO_WIDE") == nullptr;  // MZ_NO_WIDE=1 forces the 256-pixel kernel (A/B timing)
-    bool no_fuse = getenv("MZ_NO_FUSE") != nullptr;     // MZ_NO_FUSE=1 keeps conv2 and the mix as two launches
+    const Knobs knobs = h->knobs;
+    bool wide_tiles = knobs.wide;
+    bool no_fuse = !knobs.fuse;
     int io_u8 = 0;                                        // images at both ends are uint8 (mz_forward_u8)
-    bool use_s16 = getenv("MZ_NO_S16") == nullptr;        // MZ_NO_S16=1 keeps 16-bit types on the 32x32x16 kernels (A/B timing)
-    int persist_wgs = persistent_workgroups();            // 0 = MZ_NO_PERSIST: one workgroup per tile everywhere
+    bool use_s16 = knobs.s16;
+    int persist_wgs = persistent_workgroups(knobs);       // 0: one workgroup per tile everywhere
 
     void prof_begin(ProfRec*& r, double flops, double bytes, int is_conv3) {
         r = nullptr;
@@ -583,7 +608,7 @@ struct Runner {
         a.nchunks = c.nchunks;
         a.nchunks_real = c.nchunks_real;
         a.ntiles = c.ntiles;
-        a.use_glds = h ? h->use_glds : 1;
+        a.use_glds = knobs.use_glds;
     }
 
     void pick_order(ConvArgs& a, const ConvW& c, double act_bytes, int resident_per_xcd = 32) {
@@ -660,7 +685,7 @@ struct Runner {
         const double sz = dtype_size(dtype);
         const double px = (double)B * H * W;
         pick_order(a, c, px * c.cp0 * sz);
-        const bool fuse16 = epi == EPI_FUSEDMIX && mixf && mixf->packed16 && !getenv("MZ_NO_FUSE16") &&
+        const bool fuse16 = epi == EPI_FUSEDMIX && mixf && mixf->packed16 && knobs.fuse16 &&
                             (mixf->cp0 + 31) / 32 == c.nt;  // x K-steps == z K-steps (always so for C <= 96)
         if (mode != MODE_CONV3 && (epi == EPI_STORE || epi == EPI_D2S || fuse16) && persist_wgs > 0) {
             // 16-bit types: the 16x16x32-MFMA kernel (persistent only; 32-bit halo offsets span four planes)
@@ -671,7 +696,9 @@ struct Runner {
                 if (fuse16) a.wmix16 = mixf->packed16;
                 const int need = (a.grid + 7) / 8 * 8;
                 a.persist = need < persist_wgs ? need : persist_wgs;
-            } else if (a.grid > persist_wgs) {
+            } else if (a.grid > persist_wgs && (double)H * W * 32.0 < 4294967296.0) {
+                // conv3p_kernel: 32-bit halo offsets span the two planes of a 16-channel stage; larger images stay on
+                // the per-tile kernel (64-bit addresses)
                 a.persist = persist_wgs;
             }
         }
@@ -699,7 +726,7 @@ struct Runner {
         a.cp_out = pad16(c.cout);
         a.p_out = a.cp_out * sz / 16;
         a.mix_scale = 1.0f / (1.0f + std::exp(-alpha));
-        const bool mix16 = c.packed16 != nullptr && getenv("MZ_NO_MIX16") == nullptr &&
+        const bool mix16 = c.packed16 != nullptr && knobs.mix16 &&
                            (double)npix * c.cp0 * sz < 4294967296.0;  // 32-bit buffer offsets inside each tensor
         if (mix16) {  // 192-channel N tiles, x / z straight into MFMA operands (mix16_kernel)
             a.ntiles = c.cout / 192;
@@ -925,8 +952,7 @@ extern "C" int mz_op_conv(int dtype, int kind, const void* in0, const void* in1,
     // a throw-away handle carries the zero page / staging choice for Runner
     mz_handle fake;
     fake.zero_page = zero.p;
-    fake.use_glds = 1;
-    if (const char* e = getenv("MZ_USE_GLDS")) fake.use_glds = atoi(e) != 0;
+    fake.knobs = read_knobs();
     Runner run{&fake, s, dtype};
     switch (kind) {
         case 0: run.conv3(c, in0, out, B, H, W, EPI_STORE, silu, 0, 0); break;
@@ -976,8 +1002,7 @@ extern "C" int mz_op_final(int dtype, const void* feat, const void* img, const f
     if (rc) return rc;
     mz_handle fake;
     fake.zero_page = zero.p;
-    fake.use_glds = 1;
-    if (const char* e = getenv("MZ_USE_GLDS")) fake.use_glds = atoi(e) != 0;
+    fake.knobs = read_knobs();
     Runner run{&fake, s, dtype};
     run.conv3(c, feat, out, B, H, W, EPI_FINAL, 0, 2 * H, 2 * W, img, R, clamp);
     fake.zero_page = nullptr;

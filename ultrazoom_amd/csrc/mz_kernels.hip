@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(640) void conv3p_kernel(const ConvArgs a) {
                     const int py = p / G::ROWW, px = p - py * G::ROWW;
                     const int gy = y0 - 1 + py, gx = x0 - 1 + px;
                     const bool ok = (p < G::NPIX) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                    aoff[j] = ok ? (uint32_t)(((plane * a.H + gy) * a.W + gx) * 16) : 0xffffffffu;
+                    aoff[j] = ok ? (((uint32_t)plane * (uint32_t)a.H + (uint32_t)gy) * (uint32_t)a.W + (uint32_t)gx) * 16u : 0xffffffffu;  // host: planes * H * W * 16 < 2^32
                 }
             };
             set_tile(mtile);
@@ -1555,7 +1555,7 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
                     const int py = p / G::ROWW, px = p - py * G::ROWW;
                     const int gy = y0 - 1 + py, gx = x0 - 1 + px;
                     const bool ok = (p < G::NPIX) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                    aoff[j] = ok ? (uint32_t)(((plane * a.H + gy) * a.W + gx) * 16) : 0xffffffffu;
+                    aoff[j] = ok ? (((uint32_t)plane * (uint32_t)a.H + (uint32_t)gy) * (uint32_t)a.W + (uint32_t)gx) * 16u : 0xffffffffu;  // host: planes * H * W * 16 < 2^32
                 }
             };
             set_tile(mtile);

@@ -182,6 +182,9 @@ class MewZoom(nn.Module, PyTorchModelHubMixin):
         # how many images of a batch are in flight at once inside the library (0 = its default)
         self.max_images_in_flight = 0
         self._engine: Optional[_Engine] = None
+        # checkpoint-recipe compatibility (add_weight_norms / add_lora_adapters, below)
+        self._expects_weight_norm = False
+        self._lora_alphas: list = []
 
     # ---- bookkeeping identical to the reference -------------------------------------------
     @property
@@ -196,9 +199,76 @@ class MewZoom(nn.Module, PyTorchModelHubMixin):
         for p in self.parameters():
             p.requires_grad = False
 
+    def initialize_weights(self) -> None:
+        """Kaiming-uniform initialisation of every convolution weight (what model.py:104-109 intends; the reference's own
+        method stops with an AttributeError at model.py:413)."""
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                if name.endswith("conv.weight") or ".convnet.conv" in name:
+                    nn.init.kaiming_uniform_(p)
+        self.refresh_weights()
+
+    def enable_activation_checkpointing(self) -> None:
+        """Accepted for interface compatibility (model.py:141-147): a training-memory option; this class records no
+        autograd graph, so there is nothing to recompute."""
+
+    # ---- the reference's checkpoint recipe (test_compare.py:32-45, validate.py:57-67) ---------------------
+    # `model.add_weight_norms()` [-> `model.add_lora_adapters(rank, alpha)`] -> `model.load_state_dict(raw)` ->
+    # `model.remove_parameterizations()` runs unchanged against this class: the add_* calls record which training-time
+    # keys to expect, `load_state_dict` bakes them (w = g * v / ||v||, + alpha * A @ B) into the plain `conv.weight`
+    # tensors this model holds, and `remove_parameterizations` has nothing left to do.  Unlike the reference, the module
+    # tree never holds parametrised weights (it is inference-only), so `state_dict()` always has the baked layout.
+    def add_weight_norms(self) -> None:  # model.py:117-122
+        self._expects_weight_norm = True
+
+    def add_lora_adapters(self, rank: int, alpha: float) -> None:  # model.py:124-129
+        assert rank > 0, "Rank must be greater than 0."
+        assert alpha > 0.0, "Alpha must be greater than 0."
+        self._lora_alphas.append(float(alpha))
+
+    def remove_parameterizations(self) -> None:  # model.py:131-139
+        self._expects_weight_norm = False
+        self._lora_alphas = []
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        """`nn.Module.load_state_dict`, also accepting the training-time layouts announced by `add_weight_norms` /
+        `add_lora_adapters` (weight-norm `parametrizations.weight.original0/1`, LoRA `lora_a/lora_b`) and `_orig_mod.`
+        prefixes, which are baked on the way in."""
+        if any(".parametrizations." in k or k.startswith("_orig_mod.") for k in state_dict):
+            has_lora = any(k.endswith((".lora_a", ".lora_b")) for k in state_dict)
+            if has_lora and not self._lora_alphas:
+                raise RuntimeError(
+                    "Error(s) in loading state_dict for MewZoom: the checkpoint holds LoRA adapter tensors (lora_a / lora_b) "
+                    "but add_lora_adapters(rank, alpha) was not called: alpha is not stored in a checkpoint."
+                )
+            state_dict = bake_state_dict(state_dict, self._lora_alphas or None)
+        result = super().load_state_dict(state_dict, strict=strict, assign=assign)
+        self.refresh_weights()
+        return result
+
     # ---- engine management ------------------------------------------------------------------
+    def refresh_weights(self) -> None:
+        """Drops the packed copy of the weights inside the library; the next call re-packs from the parameters.
+        Needed only after writes the version counter cannot see (`p.data.copy_()` / `p.data.mul_()`, as EMA loops and some
+        optimisers do); ordinary in-place updates, `load_state_dict` and `.to()` are detected automatically."""
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+
     def _weights_signature(self) -> Tuple:
-        return tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in self.parameters())
+        def version(p):
+            try:
+                return p._version
+            except RuntimeError:  # inference tensors (created under torch.inference_mode) are not version-tracked
+                return -1
+        return tuple((p.data_ptr(), version(p), p.dtype, p.device) for p in self.parameters())
+
+    # the engine owns device memory through a C handle: copies / pickles of the module start without one (it is rebuilt
+    # lazily by _get_engine), so copy.deepcopy(model), pickle and torch.save(model) keep working after a forward
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_engine"] = None
+        return state
 
     def _get_engine(self, x: Tensor) -> "_Engine":
         if not x.is_cuda:
@@ -261,10 +331,11 @@ class MewZoom(nn.Module, PyTorchModelHubMixin):
         parametrisations (w = g * v / ||v||) and merges LoRA adapters (needs ``lora_alpha``) into plain
         ``conv.weight`` tensors -- what the reference does with ``add_weight_norms`` / ``add_lora_adapters`` ->
         ``load_state_dict`` -> ``remove_parameterizations`` (test_compare.py:32-45)."""
-        self.load_state_dict(bake_state_dict(state_dict, lora_alpha))
+        nn.Module.load_state_dict(self, bake_state_dict(state_dict, lora_alpha))
+        self.refresh_weights()
 
 
-def bake_state_dict(state_dict: Dict[str, Tensor], lora_alpha: Optional[float] = None) -> Dict[str, Tensor]:
+def bake_state_dict(state_dict: Dict[str, Tensor], lora_alpha=None) -> Dict[str, Tensor]:
     """Turns a training-time state_dict into the baked layout this model (and the HF export) uses: what the
     reference's `remove_parameterizations()` leaves behind (model.py:131-139, test_compare.py:32-45).
 
@@ -272,7 +343,8 @@ def bake_state_dict(state_dict: Dict[str, Tensor], lora_alpha: Optional[float] =
     * weight norm (`add_weight_norms`, model.py:117-122): `w = g * v / ||v||`, norm over all dims but 0;
     * LoRA adapters (`add_lora_adapters`, model.py:124-129; `ChannelLoRA.forward`, model.py:1361-1390):
       `w += alpha * (A @ B).permute(2, 3, 0, 1)` with A `[kh, kw, out, rank]`, B `[kh, kw, rank, in]`.  `alpha` is a
-      Python attribute of the adapter, not a tensor, so it is not in the checkpoint: pass it as `lora_alpha`.
+      Python attribute of the adapter, not a tensor, so it is not in the checkpoint: pass it as `lora_alpha` (one float,
+      or one per `add_lora_adapters` call in registration order).
     Parametrizations apply in registration order (weight norm can only be the first one)."""
     sd = {k.replace("_orig_mod.", ""): v for k, v in state_dict.items()}
     marker = ".parametrizations.weight."
@@ -297,11 +369,17 @@ def bake_state_dict(state_dict: Dict[str, Tensor], lora_alpha: Optional[float] =
         unknown = [leaf for leaf in leaves if not leaf.startswith("original") and not leaf.endswith((".lora_a", ".lora_b"))]
         if unknown:
             raise KeyError(f"{base}: unknown parametrization tensors {unknown}")
-        for i in adapters:
+        for n, i in enumerate(adapters):
             if lora_alpha is None:
                 raise ValueError("the checkpoint holds LoRA adapters: pass lora_alpha (the `alpha` given to add_lora_adapters)")
+            if isinstance(lora_alpha, (list, tuple)):
+                if n >= len(lora_alpha):
+                    raise ValueError(f"{base}: {len(adapters)} LoRA adapters in the checkpoint but only {len(lora_alpha)} alphas given")
+                alpha = float(lora_alpha[n])
+            else:
+                alpha = float(lora_alpha)
             a, b = leaves[f"{i}.lora_a"], leaves[f"{i}.lora_b"]
-            w = w + float(lora_alpha) * (a.to(w.dtype) @ b.to(w.dtype)).permute(2, 3, 0, 1)
+            w = w + alpha * (a.to(w.dtype) @ b.to(w.dtype)).permute(2, 3, 0, 1)
         out[base + ".weight"] = w
     return out
 
@@ -316,6 +394,9 @@ class _Engine:
         self.handle = _ffi.Handle(config, _ffi.dtype_code(dtype))
         self.config = config
         self._workspace: Optional[Tensor] = None
+        # the workspace is reused by every call: a call on another stream than the previous one waits for it
+        self._last_stream = None
+        self._last_done: Optional[torch.cuda.Event] = None
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device)
             names = dict(self.handle.weight_infos())
@@ -337,33 +418,43 @@ class _Engine:
         self.handle.close()
         self._workspace = None
 
+    def _workspace_for(self, need: int, stream) -> Tensor:
+        if self._last_done is not None and self._last_stream != stream:
+            stream.wait_event(self._last_done)
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = None
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._workspace
+
+    def _mark_done(self, stream) -> None:
+        if self._last_done is None:
+            self._last_done = torch.cuda.Event()
+        self._last_done.record(stream)
+        self._last_stream = stream
+
     def run(self, x: Tensor, clamp: bool, want_qa: bool, max_in_flight: int):
         B, _, H, W = x.shape
         r = self.config["upscale_ratio"]
         with torch.cuda.device(self.device):
-            need = self.handle.workspace_bytes(B, H, W, max_in_flight)
-            if self._workspace is None or self._workspace.numel() < need:
-                self._workspace = None
-                self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+            stream = torch.cuda.current_stream(self.device)
+            ws = self._workspace_for(self.handle.workspace_bytes(B, H, W, max_in_flight), stream)
             sr = torch.empty((B, 3, H * r, W * r), dtype=self.dtype, device=self.device)
             qa = torch.empty((B, self.config["num_deg_features"]), dtype=torch.float32, device=self.device) if want_qa else None
-            stream = torch.cuda.current_stream(self.device).cuda_stream
             self.handle.forward(
                 x.data_ptr(), sr.data_ptr(), qa.data_ptr() if want_qa else 0, B, H, W, clamp,
-                self._workspace.data_ptr(), self._workspace.numel(), max_in_flight, stream,
+                ws.data_ptr(), ws.numel(), max_in_flight, stream.cuda_stream,
             )
+            self._mark_done(stream)
         return sr, qa
 
     def run_u8(self, x: Tensor, max_in_flight: int) -> Tensor:
         B, _, H, W = x.shape
         r = self.config["upscale_ratio"]
         with torch.cuda.device(self.device):
-            need = self.handle.workspace_bytes(B, H, W, max_in_flight)
-            if self._workspace is None or self._workspace.numel() < need:
-                self._workspace = None
-                self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+            stream = torch.cuda.current_stream(self.device)
+            ws = self._workspace_for(self.handle.workspace_bytes(B, H, W, max_in_flight), stream)
             sr = torch.empty((B, 3, H * r, W * r), dtype=torch.uint8, device=self.device)
-            stream = torch.cuda.current_stream(self.device).cuda_stream
-            self.handle.forward_u8(x.data_ptr(), sr.data_ptr(), 0, B, H, W, self._workspace.data_ptr(),
-                                   self._workspace.numel(), max_in_flight, stream)
+            self.handle.forward_u8(x.data_ptr(), sr.data_ptr(), 0, B, H, W, ws.data_ptr(), ws.numel(), max_in_flight,
+                                   stream.cuda_stream)
+            self._mark_done(stream)
         return sr
