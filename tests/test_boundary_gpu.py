@@ -89,6 +89,7 @@ def test_deepcopy_after_forward_and_refresh_weights():
     assert clone._engine is None and m._engine is not None
     assert torch.equal(clone.upscale(x), y)
     # a .data write is invisible to the version counter: refresh_weights() re-packs
+    original = m.stem.conv.bias.detach().clone()
     with torch.no_grad():
         m.stem.conv.bias.data.add_(0.25)
     stale = m.upscale(x)
@@ -98,7 +99,7 @@ def test_deepcopy_after_forward_and_refresh_weights():
     assert not torch.equal(fresh, y)
     # an ordinary in-place update IS detected
     with torch.no_grad():
-        m.stem.conv.bias.sub_(0.25)
+        m.stem.conv.bias.copy_(original)
     assert torch.equal(m.upscale(x), y)
     # a model moved under inference_mode has no version counters: it still runs
     with torch.inference_mode():

@@ -30,6 +30,9 @@ F32_TOL = 1e-3
 LOWP_RATIO = 1.25      # allowed GPU error / the reference's own reduced-precision error (max-abs and RMS alike)
 MATCHED_MAX_RATIO = 1.5  # max-abs against the rounding-matched oracle's error: the maximum of a different rounding
                          # realisation over ~1e5 samples is noisier than an RMS, hence the wider factor there
+MATCHED_MIN_EQUAL = 0.70  # fraction of output elements that must equal the rounding-matched oracle BIT FOR BIT (measured on
+                          # MI355X: 80 .. 95 %, the rest one rounding step away: fp32 summation order differs); a wrong tap
+                          # weight, plane or offset anywhere in the 20 - 40 layers leaves ~0 % equal
 TAG = {torch.bfloat16: "bf16", torch.float16: "f16"}
 HALF_ULP_AT_1 = {torch.bfloat16: 2.0 ** -9, torch.float16: 2.0 ** -12}  # qa is O(0.1): its own final rounding
 
@@ -42,6 +45,7 @@ def lowp_gate_vs_matched(got: torch.Tensor, want32: torch.Tensor, matched: torch
     same = (got == matched).float().mean().item()
     print(f"{what}: max-abs {e_got:.3e} (matched oracle {e_ref:.3e}), PSNR {psnr_of(m_got):.1f} dB (matched {psnr_of(m_ref):.1f}), "
           f"{100 * same:.1f} % of the elements equal the matched oracle bit for bit")
+    assert same >= MATCHED_MIN_EQUAL, (what, same)
     assert e_got <= MATCHED_MAX_RATIO * e_ref, (what, e_got, e_ref)
     assert m_got <= LOWP_RATIO ** 2 * m_ref, (what, psnr_of(m_got), psnr_of(m_ref))
 

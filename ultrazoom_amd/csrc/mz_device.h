@@ -1,0 +1,269 @@
+// Device-side building blocks shared by the kernel translation units (mz_kernels.hip, mz_conv3q.hip): element types,
+// conversions, MFMA wrappers, LDS-DMA / LDS fragment-read primitives, the XCD-aware tile walk.
+#pragma once
+#include "mz_kernels.h"
+
+namespace mz {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct TF32 {
+    static constexpr int SZ = 4;
+    static constexpr int CK = 8;
+    static constexpr bool IS_BF16 = false;
+};
+struct TBF16 {
+    static constexpr int SZ = 2;
+    static constexpr int CK = 16;
+    static constexpr bool IS_BF16 = true;
+};
+struct TF16 {
+    static constexpr int SZ = 2;
+    static constexpr int CK = 16;
+    static constexpr bool IS_BF16 = false;
+};
+
+// ---- scalar conversions -----------------------------------------------------------------------
+template <class TT> __device__ __forceinline__ float ld1(const void* p);
+template <> __device__ __forceinline__ float ld1<TF32>(const void* p) { return *(const float*)p; }
+template <> __device__ __forceinline__ float ld1<TBF16>(const void* p) {
+    return __builtin_bit_cast(float, (uint32_t)(*(const uint16_t*)p) << 16);
+}
+template <> __device__ __forceinline__ float ld1<TF16>(const void* p) { return (float)(*(const _Float16*)p); }
+
+template <class TT> __device__ __forceinline__ void st1(void* p, float v);
+template <> __device__ __forceinline__ void st1<TF32>(void* p, float v) { *(float*)p = v; }
+template <> __device__ __forceinline__ void st1<TBF16>(void* p, float v) { *(__bf16*)p = (__bf16)v; }
+template <> __device__ __forceinline__ void st1<TF16>(void* p, float v) { *(_Float16*)p = (_Float16)v; }
+
+// image pixels at the two ends of the path: the module dtype, or uint8 with the scaling every caller of the reference
+// applies around upscale() (torchvision ToDtype(scale=True) before, save_image's mul(255).add(0.5).clamp().byte() after;
+// reference README.md:72-83, test_compare.py:53-57,89)
+template <class TT, bool U8> __device__ __forceinline__ float ld_img(const void* base, long long idx) {
+    if constexpr (U8) return (float)((const uint8_t*)base)[idx] / 255.0f;  // a true division, as ToDtype(scale=True) does
+    else return ld1<TT>((const char*)base + idx * TT::SZ);
+}
+// raw element load / conversion split, so that a batch of loads can be issued before the first conversion
+template <class TT, bool U8> __device__ __forceinline__ uint32_t ld_img_raw(const void* base, long long idx) {
+    if constexpr (U8) return ((const uint8_t*)base)[idx];
+    else if constexpr (TT::SZ == 4) return ((const uint32_t*)base)[idx];
+    else return ((const uint16_t*)base)[idx];
+}
+template <class TT, bool U8> __device__ __forceinline__ float img_cvt(uint32_t raw) {
+    if constexpr (U8) return (float)raw / 255.0f;
+    else if constexpr (TT::SZ == 4) return __builtin_bit_cast(float, raw);
+    else if constexpr (TT::IS_BF16) return __builtin_bit_cast(float, raw << 16);
+    else return (float)__builtin_bit_cast(_Float16, (uint16_t)raw);
+}
+template <class TT, bool U8> __device__ __forceinline__ void st_img(void* base, long long idx, float v) {
+    if constexpr (U8) ((uint8_t*)base)[idx] = (uint8_t)fminf(fmaxf(v * 255.0f + 0.5f, 0.0f), 255.0f);
+    else st1<TT>((char*)base + idx * TT::SZ, v);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    uint16_t lo = __builtin_bit_cast(uint16_t, (__bf16)a);
+    uint16_t hi = __builtin_bit_cast(uint16_t, (__bf16)b);
+    return (uint32_t)lo | ((uint32_t)hi << 16);
+}
+__device__ __forceinline__ uint32_t pack_f16(float a, float b) {
+    // Opaque: the value is rounded to f32 first in EVERY kernel.  Left alone, hipcc folds a preceding multiply into a
+    // v_fma_mix* form (one rounding, straight to f16) in some instantiations and not in others, and two kernels
+    // that must agree bit for bit (per-tile vs persistent, any batch size) then differ in the last f16 bit.
+    asm("" : "+v"(a), "+v"(b));
+    uint16_t lo = __builtin_bit_cast(uint16_t, (_Float16)a);
+    uint16_t hi = __builtin_bit_cast(uint16_t, (_Float16)b);
+    return (uint32_t)lo | ((uint32_t)hi << 16);
+}
+
+// 4 consecutive channels <-> memory
+template <class TT> __device__ __forceinline__ void st4(void* p, const float v[4]);
+template <> __device__ __forceinline__ void st4<TF32>(void* p, const float v[4]) {
+    *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void st4<TBF16>(void* p, const float v[4]) {
+    *(uint2*)p = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+}
+template <> __device__ __forceinline__ void st4<TF16>(void* p, const float v[4]) {
+    *(uint2*)p = make_uint2(pack_f16(v[0], v[1]), pack_f16(v[2], v[3]));
+}
+template <class TT> __device__ __forceinline__ void ld4(const void* p, float v[4]);
+template <> __device__ __forceinline__ void ld4<TF32>(const void* p, float v[4]) {
+    float4 t = *(const float4*)p;
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ __forceinline__ void ld4<TBF16>(const void* p, float v[4]) {
+    uint2 t = *(const uint2*)p;
+    v[0] = __builtin_bit_cast(float, t.x << 16);
+    v[1] = __builtin_bit_cast(float, t.x & 0xffff0000u);
+    v[2] = __builtin_bit_cast(float, t.y << 16);
+    v[3] = __builtin_bit_cast(float, t.y & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void ld4<TF16>(const void* p, float v[4]) {
+    uint2 t = *(const uint2*)p;
+    v[0] = (float)__builtin_bit_cast(_Float16, (uint16_t)(t.x & 0xffff));
+    v[1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(t.x >> 16));
+    v[2] = (float)__builtin_bit_cast(_Float16, (uint16_t)(t.y & 0xffff));
+    v[3] = (float)__builtin_bit_cast(_Float16, (uint16_t)(t.y >> 16));
+}
+
+// sigmoid with the hardware transcendental units: v_exp_f32 + v_rcp_f32 (1 ulp each) instead of an IEEE division
+__device__ __forceinline__ float sigmoidf_(float v) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+}
+
+// ---- one K-chunk of matrix work: acc[n][pixel] += W[n][k] * X[pixel][k] ------------------------
+// one 16-byte plane entry (8 channels of a 16-bit type, 4 of f32) <-> floats
+template <class TT> __device__ __forceinline__ void ld_unit(const void* p, float* v) {
+    if constexpr (TT::SZ == 4) {
+        ld4<TT>(p, v);
+    } else {
+        const uint4 t = *(const uint4*)p;
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (TT::IS_BF16) {
+                v[2 * i] = __builtin_bit_cast(float, w[i] << 16);
+                v[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u);
+            } else {
+                v[2 * i] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[i] & 0xffff));
+                v[2 * i + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[i] >> 16));
+            }
+        }
+    }
+}
+template <class TT> __device__ __forceinline__ void st_unit(void* p, const float* v) {
+    if constexpr (TT::SZ == 4) {
+        st4<TT>(p, v);
+    } else {
+        uint4 t;
+        if constexpr (TT::IS_BF16) {
+            t.x = pack_bf16(v[0], v[1]); t.y = pack_bf16(v[2], v[3]); t.z = pack_bf16(v[4], v[5]); t.w = pack_bf16(v[6], v[7]);
+        } else {
+            t.x = pack_f16(v[0], v[1]); t.y = pack_f16(v[2], v[3]); t.z = pack_f16(v[4], v[5]); t.w = pack_f16(v[6], v[7]);
+        }
+        *(uint4*)p = t;
+    }
+}
+
+template <class TT> __device__ __forceinline__ void mma(f32x16& acc, const u32x4& w, const u32x4& x);
+template <> __device__ __forceinline__ void mma<TBF16>(f32x16& acc, const u32x4& w, const u32x4& x) {
+#if defined(MZ_ABLATE) && (MZ_ABLATE & 128)
+    // timing-only (WRONG results): the same FLOPs as two v_mfma_f32_16x16x32_bf16, to price that shape's clock in situ
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    f32x4_ q0 = __builtin_shufflevector(acc, acc, 0, 1, 2, 3), q1 = __builtin_shufflevector(acc, acc, 4, 5, 6, 7);
+    q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x), q0, 0, 0, 0);
+    q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x), q1, 0, 0, 0);
+    acc[0] = q0[0]; acc[1] = q0[1]; acc[2] = q0[2]; acc[3] = q0[3];
+    acc[4] = q1[0]; acc[5] = q1[1]; acc[6] = q1[2]; acc[7] = q1[3];
+    return;
+#endif
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x),
+                                                  acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma<TF16>(f32x16& acc, const u32x4& w, const u32x4& x) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, w), __builtin_bit_cast(f16x8_t, x),
+                                                 acc, 0, 0, 0);
+}
+// f32: lane half h holds channels 4h..4h+3 of the 8-channel chunk; step e contracts {e, 4+e}.
+template <> __device__ __forceinline__ void mma<TF32>(f32x16& acc, const u32x4& w, const u32x4& x) {
+    // (bit_cast of the whole vector: __builtin_bit_cast on a single ext-vector element reads element 0)
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 wf = __builtin_bit_cast(f32x4, w), xf = __builtin_bit_cast(f32x4, x);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[0], xf[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[1], xf[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[2], xf[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[3], xf[3], acc, 0, 0, 0);
+}
+
+// LDS-DMA: 64 lanes x 16 bytes, per-lane global source, wave-uniform LDS destination.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// PyTorch's cubic convolution coefficients (A = -0.75), reference model.py:71 -> aten::upsample_bicubic2d
+__device__ __forceinline__ void cubic_coeffs(float t, float c[4]) {
+    const float A = -0.75f;
+    float x = t + 1.0f;
+    c[0] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
+    x = t;
+    c[1] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+    x = 1.0f - t;
+    c[2] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+    x = 2.0f - t;
+    c[3] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
+}
+
+// ---- LDS fragment reads hidden from hipcc's waitcnt pass ----------------------------------------
+// hipcc makes every ds_read it can see wait for ALL pending LDS-DMA (s_waitcnt vmcnt(0)), which would
+// serialise the prefetch of the next K-stage behind the current stage's first fragment read.  The
+// fragment reads of the main loop are therefore inline asm: the DMA -> read ordering is enforced by
+// hand (s_waitcnt vmcnt(0) + barrier at the end of each stage) and the read -> MFMA ordering by the
+// `wait_frags` statement, which names every destination as "+v" so no MFMA can be scheduled above it.
+// Only lgkmcnt(0) is used, so compiler-generated scalar loads in flight cannot confuse the count.
+template <int OFF> __device__ __forceinline__ u32x4 lds_read128(uint32_t addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset is 16 bits");
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+
+template <int NT> struct Frags {
+    u32x4 x0, x1;
+    u32x4 w[NT];
+};
+template <int NT> __device__ __forceinline__ void wait_frags(Frags<NT>& f) {
+    if constexpr (NT == 1)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.x0), "+v"(f.x1), "+v"(f.w[0])::"memory");
+    else if constexpr (NT == 2)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.x0), "+v"(f.x1), "+v"(f.w[0]), "+v"(f.w[1])::"memory");
+    else if constexpr (NT == 3)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.x0), "+v"(f.x1), "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2])::"memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(f.x0), "+v"(f.x1), "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3])::"memory");
+}
+
+// ================================================================================================
+// workgroup -> (pixel tile, N tile).  Consecutive logical ids land on one XCD (bijective remap of the round-robin
+// dispatch), and within an XCD's contiguous id range tiles are walked in gm x gn groups: the ~32 workgroups that are
+// resident on an XCD together then share gm activation tiles and gn weight tiles through that XCD's L2 instead of
+// re-streaming one operand per tile of the other.  Returns false for the padding ids of a partial group.
+// ================================================================================================
+// x / d for 0 <= x < 2^24 with a host-provided 1.0f / d: a handful of instructions instead of the ~30 of a runtime
+// integer division (the tile bookkeeping below ran five of them per workgroup)
+// Every caller divides wave-uniform tile ids: the quotient is returned through readfirstlane so that it (and the
+// control flow that depends on it) stays in scalar registers although the float conversion runs on the VALU.
+__device__ __forceinline__ int fdiv(int x, int d, float inv) {
+    int q = (int)((float)x * inv);
+    const int r = x - q * d;
+    q += (r >= d) - (r < 0);
+    return __builtin_amdgcn_readfirstlane(q);
+}
+
+// logical id -> tile (the group walk)
+__device__ __forceinline__ bool tile_of(const ConvArgs& a, int L, int& mtile, int& ntile) {
+    const int gsz = a.gm * a.gn;
+    const int group = fdiv(L, gsz, a.inv_gsz), within = L - group * gsz;
+    const int gi_n = fdiv(group, a.groups_m, a.inv_groups_m), gi_m = group - gi_n * a.groups_m;
+    const int mi = fdiv(within, a.gn, a.inv_gn), ni = within - mi * a.gn;
+    mtile = gi_m * a.gm + mi;
+    ntile = gi_n * a.gn + ni;
+    return mtile < a.mtiles && ntile < a.ntiles;
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <class TT> __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& w, const u32x4& x);
+template <> __device__ __forceinline__ void mma16<TBF16>(f32x4& acc, const u32x4& w, const u32x4& x) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16<TF16>(f32x4& acc, const u32x4& w, const u32x4& x) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, w), __builtin_bit_cast(f16x8_t, x), acc, 0, 0, 0);
+}
+
+}  // namespace mz

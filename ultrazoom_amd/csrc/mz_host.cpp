@@ -66,6 +66,7 @@ struct Knobs {
     bool fuse16 = true;     // MZ_NO_FUSE16=1: the fused mix stays on the 32x32x16 kernel
     bool mix16 = true;      // MZ_NO_MIX16=1: C = k * 192 mixes on the general 1x1 kernel
     int persist = -1;       // MZ_NO_PERSIST=1 -> 0 (one workgroup per tile); MZ_PERSIST_WGS=n -> n; -1 = one per CU
+    int q = 1;              // MZ_NO_Q=1: never use conv3q_kernel (one compute + one loader wave per SIMD, 8 x 48 tiles)
 };
 static Knobs read_knobs() {
     Knobs k;
@@ -75,6 +76,7 @@ static Knobs read_knobs() {
     k.s16 = getenv("MZ_NO_S16") == nullptr;
     k.fuse16 = getenv("MZ_NO_FUSE16") == nullptr;
     k.mix16 = getenv("MZ_NO_MIX16") == nullptr;
+    k.q = getenv("MZ_NO_Q") == nullptr;
     if (getenv("MZ_NO_PERSIST") != nullptr) k.persist = 0;
     else if (const char* e = getenv("MZ_PERSIST_WGS")) { const int n = atoi(e) / 8 * 8; k.persist = n > 0 ? n : 0; }
     return k;
@@ -684,6 +686,31 @@ struct Runner {
         }
         const double sz = dtype_size(dtype);
         const double px = (double)B * H * W;
+        // conv3q_kernel: one 512-register wave per SIMD, 8 x 48 pixel tiles, 96-channel N tiles
+        // (measured on the cfg3 shapes, tools/layer_bench.py: equal to conv3s_kernel where both tile shapes fit the image, 8 - 12 %
+        // faster on the 240-pixel-wide level, whose rows 48-pixel tiles cover exactly; it takes even chunk counts only)
+        bool use_q = knobs.q && use_s16 && dtype != DT_F32 && c.nt == 3 && c.packed16 && (epi == EPI_STORE || epi == EPI_D2S) &&
+                     persist_wgs > 0 && c.nchunks16 % 2 == 0 && c.nchunks16 * 32 * 8 <= c.cp0 * 9 &&
+                     (double)H * W * 64.0 < 4294967296.0;
+        if (use_q) {  // padded pixels of its 8 x 48 tiles against the better of the 8 x 64 / 16 x 32 tiles
+            const long long padq = (long long)((H + 7) / 8 * 8) * ((W + 47) / 48 * 48);
+            const long long pads = (long long)a.tiles_y * th * a.tiles_x * tw;
+            use_q = padq <= pads;
+        }
+        if (use_q) {
+            a.tiles_x = (W + 47) / 48; a.tiles_y = (H + 7) / 8;
+            a.mtiles = B * a.tiles_x * a.tiles_y;
+            pick_order(a, c, px * c.cp0 * sz);
+            a.s16 = 1; a.wpk16 = c.packed16; a.nchunks16 = c.nchunks16;
+            const int need = (a.grid + 7) / 8 * 8;
+            a.persist = need < persist_wgs ? need : persist_wgs;
+            ProfRec* r;
+            prof_begin(r, 2.0 * px * 9.0 * c.cin * c.cout, px * (c.cin + c.cout) * sz + 9.0 * c.cin * c.cout * sz, 1);
+            if (r) { r->kind = 0; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.gm * 1000 + a.gn; }
+            check(launch_conv3q(dtype, a, s), "conv3q launch");
+            prof_end(r);
+            return;
+        }
         pick_order(a, c, px * c.cp0 * sz);
         const bool fuse16 = epi == EPI_FUSEDMIX && mixf && mixf->packed16 && knobs.fuse16 &&
                             (mixf->cp0 + 31) / 32 == c.nt;  // x K-steps == z K-steps (always so for C <= 96)

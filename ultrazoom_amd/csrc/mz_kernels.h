@@ -80,7 +80,11 @@ int gemm1_chunks_per_stage();
 hipError_t launch_conv(int dtype, int mode, int nt, const ConvArgs& a, hipStream_t s);
 // AdaptiveResidualMix for C = k * 192 on the 16x16x32 MFMA (16-bit types): a.wpk16 / a.nchunks16 = K steps over [x ; z]
 hipError_t launch_mix16(int dtype, const ConvArgs& a, hipStream_t s);
-hipError_t init_kernels();  // raises the dynamic-LDS limits once per process
+hipError_t init_kernels();  // raises the dynamic-LDS limits (per device)
+// conv3q_kernel (mz_conv3q.hip): 3x3 convolution, 16-bit types, 96-channel N tiles (NT = 3), 8 x 48 pixel tiles, one
+// 512-register wave per SIMD.  a.persist workgroups of 256 threads; a.wpk16 / a.nchunks16 as for conv3s_kernel.
+hipError_t launch_conv3q(int dtype, const ConvArgs& a, hipStream_t s);
+hipError_t init_conv3q();
 
 // ---- weight packing ---------------------------------------------------------------------------
 enum OutMap : int { OUT_PLAIN = 0, OUT_D2S = 1, OUT_FINAL = 2 };
