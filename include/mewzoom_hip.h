@@ -133,6 +133,15 @@ int mz_op_stem(int dtype, const void* x, const float* w_dev_f32, const float* b_
 int mz_op_final(int dtype, const void* feat, const void* img, const float* w_dev_f32, void* out, int B, int H,
                 int W, int cin, int R, int clamp, void* hip_stream);
 
+/* a17 of SURVEY.md section 8 -- NO reference counterpart: the snapshot (v0.3.0) has no ControlModule / FiLM (README.md:86-129
+ * describes library version 0.2.x, whose source is absent), so this operator is "parity unpinned": it is checked against the
+ * build's own CPU restatement (oracle.film_conv) only.   out = act(gamma[b, c] * conv3x3(in0, w)[b, c] + beta[b, c]),
+ * act = SiLU when silu != 0.  gamma, beta: float32 [B][cout] on the device.  bf16 / fp16 only (the epilogue lives on the
+ * 16x16x32 kernel); other configurations return MZ_ERR_INVALID_ARGUMENT. */
+int mz_op_conv_film(int dtype, const void* in0, const float* w_dev_f32, const float* gamma_dev_f32,
+                    const float* beta_dev_f32, void* out, int B, int H, int W, int cin, int cout, int silu,
+                    void* hip_stream);
+
 /* ---- introspection ------------------------------------------------------------------------ */
 const char* mz_last_error(void);
 const char* mz_version(void);

@@ -219,6 +219,14 @@ def fit_to(x: Tensor, size: Tuple[int, int]) -> Tensor:
     return x
 
 
+def film_conv(x: Tensor, w: Tensor, gamma: Tensor, beta: Tensor, silu: bool = False) -> Tensor:
+    """NO REFERENCE COUNTERPART: the v0.3.0 snapshot has no ControlModule / FiLM.  The build's own
+    statement of the per-channel modulation its optional epilogue computes, for the GPU test of that epilogue only:
+    act(gamma[b, c] * conv3x3(x, w)[b, c] + beta[b, c]) with gamma, beta of shape [B, C]."""
+    y = F.conv2d(x, w, padding=1) * gamma[:, :, None, None] + beta[:, :, None, None]
+    return F.silu(y) if silu else y
+
+
 def quality_head(z4: Tensor, w: Tensor, b: Tensor) -> Tensor:
     """QualityAssessor.forward, model.py:1026-1032: conv3x3 + bias, global spatial mean."""
     return F.conv2d(z4, w, b, padding=1).mean(dim=(2, 3))

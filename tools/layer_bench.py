@@ -11,7 +11,7 @@ from bench import MODELS, parameter_shapes
 from ultrazoom_amd import MewZoom
 from ultrazoom_amd.synth import synth_image, synth_state_dict
 
-VARIANTS = {"base": {"MZ_NO_Q": "1"}, "q": {}}
+VARIANTS = {"base": {}, "kpad34": {"MZ_KPAD_PCT": "34"}}
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 workload = sys.argv[2] if len(sys.argv) > 2 else "cfg3"
 if workload == "cfg2":
@@ -23,7 +23,7 @@ else:
 sd = synth_state_dict(parameter_shapes(cfg), seed=1234)
 models = {}
 for name, env in VARIANTS.items():
-    for k in ("MZ_Q", "MZ_NO_Q"):
+    for k in ("MZ_Q", "MZ_NO_Q", "MZ_NO_BLK4", "MZ_KPAD_PCT"):
         os.environ.pop(k, None)
     os.environ.update(env)
     m = MewZoom(**cfg); m.load_state_dict(sd); m = m.to("cuda", torch.bfloat16).eval()

@@ -59,6 +59,8 @@ def _declare(lib) -> None:
     lib.mz_forward_u8.restype = c_int
     lib.mz_padded_channels.argtypes = [c_int]
     lib.mz_op_conv.argtypes = [c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p] + [c_int] * 8 + [c_void_p]
+    lib.mz_op_conv_film.argtypes = [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]
+    lib.mz_op_conv_film.restype = c_int
     lib.mz_op_stem.argtypes = [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     lib.mz_op_final.argtypes = [c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]
     lib.mz_last_error.restype = c_char_p

@@ -209,9 +209,10 @@ __global__ __launch_bounds__(512) void conv3q_kernel(const ConvArgs a) {
     auto tile_origin = [&](int mt, int& b, int& y0, int& x0) __attribute__((always_inline)) {
         b = fdiv(mt, tpi, a.inv_tpi);
         const int trem = mt - b * tpi;
-        const int tyi = fdiv(trem, a.tiles_x, a.inv_tiles_x);
+        int tyi, txi;
+        tile_rc(a, trem, tyi, txi);
         y0 = tyi * TH;
-        x0 = (trem - tyi * a.tiles_x) * TW;
+        x0 = txi * TW;
     };
 
     if (w >= 4) {

@@ -266,4 +266,25 @@ template <> __device__ __forceinline__ void mma16<TF16>(f32x4& acc, const u32x4&
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, w), __builtin_bit_cast(f16x8_t, x), acc, 0, 0, 0);
 }
 
+// Tile index inside an image -> (tile row, tile column).  a.blk4 = 0: row-major.  a.blk4 = 1: block rows of FOUR tile rows walked
+// column by column, so that the ~32 workgroups that run on one XCD at a time (consecutive tile ids) cover a 4 x 8 block of tiles
+// instead of a 1 x 32 strip: the halo rows between vertically adjacent tiles are then shared through that XCD's L2 instead of
+// being fetched again a whole tile row later (input fetch 10/8 -> 34/32 of the compulsory bytes for 8-row tiles).
+__device__ __forceinline__ void tile_rc(const ConvArgs& a, int trem, int& tyi, int& txi) {
+    if (!a.blk4) {
+        tyi = fdiv(trem, a.tiles_x, a.inv_tiles_x);
+        txi = trem - tyi * a.tiles_x;
+        return;
+    }
+    const int bsz = 4 * a.tiles_x;
+    const int br = fdiv(trem, bsz, a.inv_bsz);
+    const int rem = trem - br * bsz;
+    int rows = a.tiles_y - 4 * br;  // tile rows of this block row: 4, or 1..3 for the last one
+    rows = rows < 4 ? rows : 4;
+    // rem / rows for rows in 1..4 (rem < 2^16: at most 4 * tiles_x tiles per block row)
+    const int qx = rows == 4 ? rem >> 2 : (rows == 3 ? (int)(((unsigned)rem * 43691u) >> 17) : (rows == 2 ? rem >> 1 : rem));
+    txi = __builtin_amdgcn_readfirstlane(qx);
+    tyi = 4 * br + rem - txi * rows;
+}
+
 }  // namespace mz

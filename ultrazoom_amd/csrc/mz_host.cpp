@@ -66,6 +66,8 @@ struct Knobs {
     bool fuse16 = true;     // MZ_NO_FUSE16=1: the fused mix stays on the 32x32x16 kernel
     bool mix16 = true;      // MZ_NO_MIX16=1: C = k * 192 mixes on the general 1x1 kernel
     int persist = -1;       // MZ_NO_PERSIST=1 -> 0 (one workgroup per tile); MZ_PERSIST_WGS=n -> n; -1 = one per CU
+    int kpad_pct = 12;      // MZ_KPAD_PCT=n: the 16x16x32 kernels take Cin whose padding to whole 32-channel chunks is <= n %
+    int blk4 = 1;           // MZ_NO_BLK4=1: row-major tile walk inside an image (A/B of the L2 sharing of vertical halos)
     int q = 1;              // MZ_NO_Q=1: never use conv3q_kernel (one compute + one loader wave per SIMD, 8 x 48 tiles)
 };
 static Knobs read_knobs() {
@@ -77,6 +79,8 @@ static Knobs read_knobs() {
     k.fuse16 = getenv("MZ_NO_FUSE16") == nullptr;
     k.mix16 = getenv("MZ_NO_MIX16") == nullptr;
     k.q = getenv("MZ_NO_Q") == nullptr;
+    k.blk4 = getenv("MZ_NO_BLK4") == nullptr;
+    if (const char* e = getenv("MZ_KPAD_PCT")) k.kpad_pct = atoi(e);
     if (getenv("MZ_NO_PERSIST") != nullptr) k.persist = 0;
     else if (const char* e = getenv("MZ_PERSIST_WGS")) { const int n = atoi(e) / 8 * 8; k.persist = n > 0 ? n : 0; }
     return k;
@@ -577,6 +581,8 @@ struct Runner {
     bool wide_tiles = knobs.wide;
     bool no_fuse = !knobs.fuse;
     int io_u8 = 0;                                        // images at both ends are uint8 (mz_forward_u8)
+    const float* film_gamma = nullptr;                    // mz_op_conv_film: per-image per-channel affine on the next conv3 call
+    const float* film_beta = nullptr;
     bool use_s16 = knobs.s16;
     int persist_wgs = persistent_workgroups(knobs);       // 0: one workgroup per tile everywhere
 
@@ -639,6 +645,8 @@ struct Runner {
         a.inv_gn = 1.0f / (float)a.gn;
         a.inv_tpi = a.tiles_x > 0 ? 1.0f / (float)(a.tiles_x * a.tiles_y) : 1.0f;
         a.inv_tiles_x = a.tiles_x > 0 ? 1.0f / (float)a.tiles_x : 1.0f;
+        a.inv_bsz = a.tiles_x > 0 ? 1.0f / (float)(4 * a.tiles_x) : 1.0f;
+        a.blk4 = knobs.blk4 && a.tiles_x > 0 && 4 * a.tiles_x < 65536 ? 1 : 0;  // read by conv3s_kernel / conv3q_kernel only
     }
 
     // conv3x3, pad 1 (model.py:742-748, 900-909, 1010). epi: STORE / D2S / FINAL
@@ -689,8 +697,8 @@ struct Runner {
         // conv3q_kernel: one 512-register wave per SIMD, 8 x 48 pixel tiles, 96-channel N tiles
         // (measured on the cfg3 shapes, tools/layer_bench.py: equal to conv3s_kernel where both tile shapes fit the image, 8 - 12 %
         // faster on the 240-pixel-wide level, whose rows 48-pixel tiles cover exactly; it takes even chunk counts only)
-        bool use_q = knobs.q && use_s16 && dtype != DT_F32 && c.nt == 3 && c.packed16 && (epi == EPI_STORE || epi == EPI_D2S) &&
-                     persist_wgs > 0 && c.nchunks16 % 2 == 0 && c.nchunks16 * 32 * 8 <= c.cp0 * 9 &&
+        bool use_q = knobs.q && use_s16 && !film_gamma && dtype != DT_F32 && c.nt == 3 && c.packed16 && (epi == EPI_STORE || epi == EPI_D2S) &&
+                     persist_wgs > 0 && c.nchunks16 % 2 == 0 && c.nchunks16 * 32 * 100 <= c.cp0 * (100 + knobs.kpad_pct) &&
                      (double)H * W * 64.0 < 4294967296.0;
         if (use_q) {  // padded pixels of its 8 x 48 tiles against the better of the 8 x 64 / 16 x 32 tiles
             const long long padq = (long long)((H + 7) / 8 * 8) * ((W + 47) / 48 * 48);
@@ -717,7 +725,7 @@ struct Runner {
         if (mode != MODE_CONV3 && (epi == EPI_STORE || epi == EPI_D2S || fuse16) && persist_wgs > 0) {
             // 16-bit types: the 16x16x32-MFMA kernel (persistent only; 32-bit halo offsets span four planes)
             // ... and only where padding K to whole 32-channel chunks wastes less than the shape gains (~12 %)
-            const bool k_fits = c.nchunks16 * 32 * 8 <= c.cp0 * 9;
+            const bool k_fits = c.nchunks16 * 32 * 100 <= c.cp0 * (100 + knobs.kpad_pct);
             if (c.packed16 && use_s16 && k_fits && (double)H * W * 64.0 < 4294967296.0) {
                 a.s16 = 1; a.wpk16 = c.packed16; a.nchunks16 = c.nchunks16;
                 if (fuse16) a.wmix16 = mixf->packed16;
@@ -729,8 +737,18 @@ struct Runner {
                 a.persist = persist_wgs;
             }
         }
+        if (film_gamma) {
+            if (!a.s16) {
+                rc = fail(MZ_ERR_INVALID_ARGUMENT, "the FiLM epilogue exists on the 16x16x32 kernel only: bf16 / fp16, at most 96 output "
+                                                   "channels per N tile, input channels within 12.5 %% of a multiple of 32");
+                return;
+            }
+            a.film_gamma = film_gamma; a.film_beta = film_beta;
+        }
+        // algorithmic bytes: input once, output once, weights once; a fused conv2 + mix also reads the block input x once
+        const double extra_bytes = epi == EPI_FUSEDMIX ? px * c.cout * sz : 0.0;
         ProfRec* r;
-        prof_begin(r, 2.0 * px * 9.0 * c.cin * c.cout + extra_flops, px * (c.cin + c.cout) * sz + 9.0 * c.cin * c.cout * sz, 1);
+        prof_begin(r, 2.0 * px * 9.0 * c.cin * c.cout + extra_flops, px * (c.cin + c.cout) * sz + 9.0 * c.cin * c.cout * sz + extra_bytes, 1);
         if (r) { r->kind = 0; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.gm * 1000 + a.gn; }
         check(launch_conv(dtype, mode, c.nt, a, s), "conv3x3 launch");
         prof_end(r);
@@ -993,6 +1011,46 @@ extern "C" int mz_op_conv(int dtype, int kind, const void* in0, const void* in1,
         case 2: run.crush(c, in0, out, B, H, W); break;
         case 3: run.mix(c, alpha, in0, in1, out, B, H, W); break;
     }
+    fake.zero_page = nullptr;
+    HIPCHK(hipStreamSynchronize(s));
+    return run.rc;
+}
+
+// a17: conv3x3 -> gamma[b, c] * y + beta[b, c] -> optional SiLU, the per-channel modulation of a FiLM /
+// control module.  The reference snapshot has no such module (README.md:86-129 describes library version 0.2.x): nothing to
+// be parity-checked against, so this operator is checked against the build's own CPU restatement only ("parity unpinned").
+extern "C" int mz_op_conv_film(int dtype, const void* in0, const float* w_dev_f32, const float* gamma_dev_f32,
+                               const float* beta_dev_f32, void* out, int B, int H, int W, int cin, int cout, int silu,
+                               void* hip_stream) {
+    int rc = ensure_device_ready();
+    if (rc) return rc;
+    if (!in0 || !w_dev_f32 || !gamma_dev_f32 || !beta_dev_f32 || !out) return fail(MZ_ERR_INVALID_ARGUMENT, "null argument");
+    if (dtype != DT_BF16 && dtype != DT_F16) return fail(MZ_ERR_INVALID_ARGUMENT, "the FiLM epilogue is implemented for bf16 / fp16");
+    hipStream_t s = (hipStream_t)hip_stream;
+    ConvW c;
+    plan_conv(c, dtype, MODE_CONV3, cout, cin, 3, 3, OUT_PLAIN, SRC_PLAIN, 0, 0);
+    TempBuf zero, packed, packed16, gpad, bpad;
+    HIPCHK(hipMalloc(&zero.p, 4096));
+    HIPCHK(hipMemsetAsync(zero.p, 0, 4096, s));
+    rc = pack_conv(c, dtype, w_dev_f32, s);
+    packed.p = c.packed;
+    packed16.p = c.packed16;
+    if (rc) return rc;
+    // gamma / beta [B][cout] -> [B][padded cout], pad channels zero
+    const int cp = pad16(cout);
+    HIPCHK(hipMalloc(&gpad.p, sizeof(float) * (size_t)B * cp));
+    HIPCHK(hipMalloc(&bpad.p, sizeof(float) * (size_t)B * cp));
+    HIPCHK(hipMemsetAsync(gpad.p, 0, sizeof(float) * (size_t)B * cp, s));
+    HIPCHK(hipMemsetAsync(bpad.p, 0, sizeof(float) * (size_t)B * cp, s));
+    HIPCHK(hipMemcpy2DAsync(gpad.p, sizeof(float) * cp, gamma_dev_f32, sizeof(float) * cout, sizeof(float) * cout, B, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpy2DAsync(bpad.p, sizeof(float) * cp, beta_dev_f32, sizeof(float) * cout, sizeof(float) * cout, B, hipMemcpyDeviceToDevice, s));
+    mz_handle fake;
+    fake.zero_page = zero.p;
+    fake.knobs = read_knobs();
+    Runner run{&fake, s, dtype};
+    run.film_gamma = (const float*)gpad.p;
+    run.film_beta = (const float*)bpad.p;
+    run.conv3(c, in0, out, B, H, W, EPI_STORE, silu, 0, 0);
     fake.zero_page = nullptr;
     HIPCHK(hipStreamSynchronize(s));
     return run.rc;

@@ -55,6 +55,8 @@ struct ConvArgs {
     int grid;          // workgroups launched: whole groups, >= mtiles * ntiles
     int groups_m;      // ceil(mtiles / gm)
     float inv_gsz, inv_groups_m, inv_gn, inv_tpi, inv_tiles_x;  // 1.0f / divisor for fdiv() (all dividends < 2^24)
+    int blk4;          // conv3s / conv3q: tiles of an image are walked in block rows of four tile rows (tile_rc(), mz_device.h)
+    float inv_bsz;     // 1.0f / (4 * tiles_x)
     int epi;
     int silu;
     int cp_out;        // STORE/MIX: padded channels of out; D2S: channels per output pixel (cq_p)
@@ -69,6 +71,8 @@ struct ConvArgs {
     const void* wpk16; // weights packed for it: [ntile][32-channel chunk][tap][2*nt][64 lanes][16 B]
     int nchunks16;     // 32-channel chunks
     const void* wmix16; // EPI_FUSEDMIX on the 16x16x32 kernel: gate weights packed [2*nt K-steps][2*nt][64 lanes][16 B]
+    const float* film_gamma;  // EPI_STORE on conv3s_kernel only: per-image per-channel affine gamma * y + beta ahead of the SiLU
+    const float* film_beta;   //   (float [B][cp_out], pad channels zero); nullptr = off.  No reference counterpart.
     int use_glds;      // stage through global_load_lds (1) or through registers (0)
     unsigned long long* dbg;  // -DMZ_STAMP diagnostic builds: per-stage s_memtime stamps of one workgroup
 };

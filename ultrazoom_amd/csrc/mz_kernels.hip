@@ -1060,7 +1060,9 @@ __device__ __forceinline__ void s16_back(f32x4 (&acc)[4][2 * NT], Frag16& f, uin
 // accumulators -> plane-major tensor.  Lane (g, c) holds channels 4g..4g+3 of pixel c of each 16-channel fragment;
 // v_permlane16_swap between the two fragments of a group leaves lane g with one full 16-byte plane entry:
 // fragment (g & 1) of the pair, plane (g >> 1) of that fragment.
-template <class TT, int NT, int MODE, int EPI, bool SILU>
+// FILM (NO reference counterpart in the snapshot): a per-image, per-channel affine gamma * y + beta on the
+// convolution result, ahead of the optional SiLU -- the shape of a FiLM / control-module modulation.
+template <class TT, int NT, int MODE, int EPI, bool SILU, bool FILM = false>
 __device__ __forceinline__ void store_frag16(const ConvArgs& a, f32x4 (&accpf)[2 * NT], const int pf, int lane, int w, int nbase,
                                              int b, int y0, int x0) {
     using G = Geo<MODE>;
@@ -1085,7 +1087,7 @@ __device__ __forceinline__ void store_frag16(const ConvArgs& a, f32x4 (&accpf)[2
         }
         const int cu = 2 * (2 * n + (g & 1)) + (g >> 1);  // 16-byte unit inside this workgroup's BN channels
         const int nch = nbase + cu * 8;
-        if constexpr (SILU) {
+        if constexpr (SILU && !FILM) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = v[j] * sigmoidf_(v[j]);
         }
@@ -1101,14 +1103,26 @@ __device__ __forceinline__ void store_frag16(const ConvArgs& a, f32x4 (&accpf)[2
             if (nch >= a.cp_out) continue;
             dst = obase + (nch >> 3) * plane_o + ((long long)py * a.W + px) * 16;
         }
+        if constexpr (FILM) {  // gamma / beta: float [B][cp_out], pad channels zero (the host pads them)
+            const float4* gp = (const float4*)(a.film_gamma + (long long)b * a.cp_out + nch);
+            const float4* bp = (const float4*)(a.film_beta + (long long)b * a.cp_out + nch);
+            const float4 g0 = gp[0], g1 = gp[1], b0 = bp[0], b1 = bp[1];
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[j] = gg[j] * v[j] + bb[j];
+                if constexpr (SILU) v[j] = v[j] * sigmoidf_(v[j]);
+            }
+        }
         st_unit<TT>(dst, v);
     }
 }
-template <class TT, int NT, int MODE, int EPI, bool SILU>
+template <class TT, int NT, int MODE, int EPI, bool SILU, bool FILM = false>
 __device__ __forceinline__ void store_epilogue16(const ConvArgs& a, f32x4 (&acc)[4][2 * NT], int lane, int w, int nbase, int b,
                                                  int y0, int x0) {
 #pragma unroll
-    for (int pf = 0; pf < 4; ++pf) store_frag16<TT, NT, MODE, EPI, SILU>(a, acc[pf], pf, lane, w, nbase, b, y0, x0);
+    for (int pf = 0; pf < 4; ++pf) store_frag16<TT, NT, MODE, EPI, SILU, FILM>(a, acc[pf], pf, lane, w, nbase, b, y0, x0);
 }
 
 // -DMZ_STAMP=2 diagnostic build: where the waves of one workgroup spend each half-chunk (tools/stamp_probe16.py)
@@ -1217,9 +1231,10 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
     auto tile_origin = [&](int mt, int& b, int& y0, int& x0) __attribute__((always_inline)) {
         b = fdiv(mt, tpi, a.inv_tpi);
         const int trem = mt - b * tpi;
-        const int tyi = fdiv(trem, a.tiles_x, a.inv_tiles_x);
+        int tyi, txi;
+        tile_rc(a, trem, tyi, txi);
         y0 = tyi * G::TH;
-        x0 = (trem - tyi * a.tiles_x) * G::TW;
+        x0 = txi * G::TW;
     };
 
     if (w >= 8) {
@@ -1456,6 +1471,10 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
             }
         } else
         if (a.epi == EPI_D2S) store_epilogue16<TT, NT, MODE, EPI_D2S, false>(a, acc, lane, w, nbase, b, y0, x0);
+        else if (a.film_gamma) {
+            if (a.silu) store_epilogue16<TT, NT, MODE, EPI_STORE, true, true>(a, acc, lane, w, nbase, b, y0, x0);
+            else store_epilogue16<TT, NT, MODE, EPI_STORE, false, true>(a, acc, lane, w, nbase, b, y0, x0);
+        }
         else if (a.silu) store_epilogue16<TT, NT, MODE, EPI_STORE, true>(a, acc, lane, w, nbase, b, y0, x0);
         else store_epilogue16<TT, NT, MODE, EPI_STORE, false>(a, acc, lane, w, nbase, b, y0, x0);
         cur = seek(cur + step, mtile, ntile);
