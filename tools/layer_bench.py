@@ -11,7 +11,7 @@ from bench import MODELS, parameter_shapes
 from ultrazoom_amd import MewZoom
 from ultrazoom_amd.synth import synth_image, synth_state_dict
 
-VARIANTS = {"base": {}, "kpad34": {"MZ_KPAD_PCT": "34"}}
+VARIANTS = {"base": {"MZ_NO_Q": "1"}, "q": {}}
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 workload = sys.argv[2] if len(sys.argv) > 2 else "cfg3"
 if workload == "cfg2":

@@ -299,10 +299,15 @@ __global__ __launch_bounds__(512) void conv3q_kernel(const ConvArgs a) {
         advance_load();
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-#ifdef Q_ABLATE_DMA
-#define Q_ISSUE(x) do { } while (0)
+#if defined(Q_ABLATE_DMA) || defined(Q_ABLATE_H)   // -DQ_ABLATE_H / -DQ_ABLATE_W: only the halo / only the weight loads are dropped
+#define Q_ISSUE_H(x) do { } while (0)
 #else
-#define Q_ISSUE(x) x
+#define Q_ISSUE_H(x) x
+#endif
+#if defined(Q_ABLATE_DMA) || defined(Q_ABLATE_W)
+#define Q_ISSUE_W(x) do { } while (0)
+#else
+#define Q_ISSUE_W(x) x
 #endif
 #ifdef Q_ABLATE_WAIT
 #define Q_WAIT() do { } while (0)
@@ -311,13 +316,13 @@ __global__ __launch_bounds__(512) void conv3q_kernel(const ConvArgs a) {
 #endif
         for (int h = 0; h < nhalf; h += 2) {
             // first half of a chunk: the NEXT chunk's halo image and first weight half
-            Q_ISSUE(issue_halo(hal_nxt));
-            Q_ISSUE(issue_weights(0, ws_nn));
+            Q_ISSUE_H(issue_halo(hal_nxt));
+            Q_ISSUE_W(issue_weights(0, ws_nn));
             Q_WAIT();
             __builtin_amdgcn_s_barrier();
             { char* t_ = ws_cur; ws_cur = ws_nxt; ws_nxt = ws_nn; ws_nn = t_; }
             // second half: the next chunk's second weight half
-            Q_ISSUE(issue_weights(1, ws_nn));
+            Q_ISSUE_W(issue_weights(1, ws_nn));
             advance_load();
             Q_WAIT();
             __builtin_amdgcn_s_barrier();
