@@ -20,7 +20,7 @@ Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
                  dense bf16 MFMA peak of 2.5 PFLOP/s (`frac`) AND against what this very device sustains on a bare,
                  register-resident MFMA loop with random operands, measured in the same run by tools/microbench/mb_mfma
                  (`measured_peak`, `frac_of_measured_peak`).  `traffic` comes from committed rocprofv3 PMC passes and is
-                 only quoted when they were taken with the library that is running (sha256 match).
+                 only quoted when they were taken with the kernel sources that are running (sha256 match).
   cpu_baseline : the CPU oracle (oracle/mewzoom_oracle.py, torch CPU fp32 on all host cores): `value` is timed on a
                  bounded sample of the SAME model as the GPU workload (with the GPU-vs-oracle PSNR / max-abs on that
                  sample), `cfg1` is BASELINE.md section 3's procedure (2X-48 model, 1x3x256x256, median of >= 5).
@@ -92,10 +92,15 @@ def host_cores() -> int:
 TRAFFIC_PROFILE = REPO / "profiles" / "r02_pmc_traffic_conv3x3.json"
 
 
-def library_sha256() -> str:
-    from ultrazoom_amd import _ffi
-
-    return hashlib.sha256(Path(os.environ.get("MEWZOOM_HIP_LIB", _ffi.LIB_PATH)).read_bytes()).hexdigest()
+def kernel_source_sha256() -> str:
+    """Identity of the kernel build: sha256 over the sources of libmewzoom_hip.so (stable across rebuilds of the same tree,
+    unlike the binary).  A PMC profile is only quoted next to a run of the sources it was taken with."""
+    h = hashlib.sha256()
+    for f in sorted((REPO / "ultrazoom_amd" / "csrc").glob("mz_*")):
+        if f.suffix in (".hip", ".cpp", ".h"):
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()
 
 
 def traffic_from_profile(args):
@@ -110,8 +115,8 @@ def traffic_from_profile(args):
         return None, f"{TRAFFIC_PROFILE.name} not found"
     try:
         prof = json.loads(TRAFFIC_PROFILE.read_text())
-        if prof.get("library_sha256") != library_sha256():
-            return None, "stale PMC profile: it was taken with a different build of libmewzoom_hip.so"
+        if prof.get("kernel_source_sha256") != kernel_source_sha256():
+            return None, "stale PMC profile: it was taken with different kernel sources (ultrazoom_amd/csrc)"
         return prof, None
     except (OSError, KeyError, ValueError) as e:
         return None, f"unreadable PMC profile: {e}"
@@ -334,7 +339,7 @@ def main():
                 # bytes per launch (each conv reads its input once and writes its output once, weights once)
                 "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
                 "traffic_note": pmc_note or f"{TRAFFIC_PROFILE.name}: {pmc['launches']} launches of one {pmc.get('images', 3)}-image "
-                                            "micro-batch forward, same library build (sha256 match)",
+                                            "micro-batch forward, same kernel sources (sha256 match)",
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                 "traffic_over_algorithmic": pmc["traffic_bytes_per_launch"] / alg_bytes_per_launch if pmc and alg_bytes_per_launch else None,
                 "traffic_bytes_per_step": pmc["traffic_bytes_per_launch"] * prof["conv_launches"] if pmc else None,

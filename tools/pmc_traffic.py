@@ -5,8 +5,9 @@ streams -> doubled; WRITE_SIZE is exact for 16-byte-per-lane stores.  Both count
 import csv, glob, hashlib, json, sys, os, collections
 root = sys.argv[1]
 repo = os.environ.get("GRAFT_REPO_ROOT", os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-lib = os.path.join(repo, "ultrazoom_amd", "libmewzoom_hip.so")
-lib_sha = hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None
+sys.path.insert(0, repo)
+from bench import kernel_source_sha256  # identity of the kernels the profile was taken with (sources, not the binary)
+lib_sha = kernel_source_sha256()
 tot = collections.defaultdict(float); n = collections.defaultdict(set)
 for cname, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     for f in glob.glob(os.path.join(root, sub, "*", "*_counter_collection.csv")):
@@ -17,7 +18,7 @@ launches = len(n["FETCH_SIZE"]) or 1
 fetch = 2.0 * tot["FETCH_SIZE"] * 1024 / launches
 write = tot["WRITE_SIZE"] * 1024 / max(1, len(n["WRITE_SIZE"]))
 out = {"kernel": "3x3 convolution kernels (every 3x3 launch of one 3-image micro-batch forward, cfg3 1080p, bf16)",
-       "library_sha256": lib_sha, "images": 3,
+       "kernel_source_sha256": lib_sha, "images": 3,
        "launches": launches, "fetch_bytes_per_launch_corrected_x2": fetch, "write_bytes_per_launch": write,
        "traffic_bytes_per_launch": fetch + write,
        "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); Infinity-Cache hits are included in FETCH_SIZE"}
