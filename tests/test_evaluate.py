@@ -1,4 +1,4 @@
-"""The PSNR / SSIM harness.  torchmetrics is absent here, so the restatement is checked against an
+"""The PSNR / SSIM / VIF harness.  torchmetrics is absent here, so the restatement is checked against an
 independent numpy/scipy computation of the same published definitions."""
 
 import math
@@ -8,7 +8,7 @@ import pytest
 import torch
 from scipy.ndimage import correlate1d
 
-from ultrazoom_amd.evaluate import PSNR, SSIM, evaluate, ssim_per_image
+from ultrazoom_amd.evaluate import PSNR, SSIM, VIF, evaluate, ssim_per_image, vif_per_image
 from ultrazoom_amd.synth import synth_image
 
 
@@ -55,6 +55,55 @@ def test_ssim_matches_independent_restatement():
     assert 0.5 < m.compute() < 1.0
 
 
+def _vif_numpy(p, t, sigma_n_sq=2.0):
+    """Pixel-domain VIF of one channel, written independently with scipy (valid-mode Gaussian filtering by cropping)."""
+    from scipy.ndimage import correlate
+
+    num = den = 0.0
+    for scale in range(4):
+        n = 2 ** (4 - scale) + 1
+        x = np.arange(n) - (n - 1) / 2.0
+        k = np.exp(-(x[:, None] ** 2 + x[None, :] ** 2) / (2.0 * (n / 5.0) ** 2))
+        k /= k.sum()
+        h = n // 2
+        valid = lambda z: correlate(z, k, mode="constant")[h:-h, h:-h]
+        if scale > 0:
+            t, p = valid(t)[::2, ::2], valid(p)[::2, ::2]
+        mt, mp = valid(t), valid(p)
+        stt = np.maximum(valid(t * t) - mt * mt, 0.0)
+        spp = np.maximum(valid(p * p) - mp * mp, 0.0)
+        stp = valid(t * p) - mt * mp
+        g = stp / (stt + 1e-10)
+        sv = spp - g * stp
+        m = stt < 1e-10
+        g[m] = 0.0; sv[m] = spp[m]; stt[m] = 0.0
+        m = spp < 1e-10
+        g[m] = 0.0; sv[m] = 0.0
+        m = g < 0
+        sv[m] = spp[m]; g[m] = 0.0
+        sv = np.maximum(sv, 1e-10)
+        num += np.log10(1.0 + g * g * stt / (sv + sigma_n_sq)).sum()
+        den += np.log10(1.0 + stt / sigma_n_sq).sum()
+    return num / den
+
+
+def test_vif_matches_independent_restatement():
+    t = synth_image(2, 64, 80, seed=7)
+    p = (t + 0.08 * (synth_image(2, 64, 80, seed=8) - 0.5)).clamp(0, 1)
+    got = vif_per_image(p, t)
+    for b in range(2):
+        want = np.mean([_vif_numpy(p[b, c].double().numpy(), t[b, c].double().numpy()) for c in range(3)])
+        assert math.isclose(float(got[b]), want, rel_tol=1e-9), (float(got[b]), want)
+    assert torch.allclose(vif_per_image(t, t), torch.ones(2, dtype=torch.float64), atol=1e-9)  # identical images: fidelity 1
+    blurred = torch.nn.functional.avg_pool2d(t, 3, stride=1, padding=1)
+    assert float(vif_per_image(blurred, t).max()) < 1.0   # lost detail = lost information
+    m = VIF()
+    m.update(p, t)
+    assert math.isclose(m.compute(), float(got.mean()), rel_tol=1e-12)
+    with pytest.raises(ValueError, match="41"):
+        vif_per_image(t[:, :, :32, :32], t[:, :, :32, :32])
+
+
 def test_evaluate_loop_with_a_stand_in_model():
     class Nearest:
         def upscale(self, x):
@@ -63,7 +112,7 @@ def test_evaluate_loop_with_a_stand_in_model():
     hr = synth_image(3, 32, 32, seed=5)
     lr = hr[:, :, ::2, ::2]
     r = evaluate(Nearest(), [(lr[:2], hr[:2]), (lr[2:], hr[2:])])
-    assert r["images"] == 3 and 5.0 < r["psnr"] < 40.0 and -1.0 <= r["ssim"] <= 1.0
+    assert r["images"] == 3 and 5.0 < r["psnr"] < 40.0 and -1.0 <= r["ssim"] <= 1.0 and r["vif"] is None  # 32 x 32 < 41
 
 
 @pytest.mark.gpu
@@ -79,4 +128,4 @@ def test_evaluate_on_the_hip_model_against_the_oracle():
     x = synth_image(2, 40, 56, seed=6)
     want = oracle.upscale(case.config, case.weights(), x)  # the "ground truth" of this check: the CPU oracle's output
     r = evaluate(m, [(x.cuda(), want.cuda())])
-    assert r["images"] == 2 and r["psnr"] > 100.0 and r["ssim"] > 0.999999
+    assert r["images"] == 2 and r["psnr"] > 100.0 and r["ssim"] > 0.999999 and abs(r["vif"] - 1.0) < 1e-3
