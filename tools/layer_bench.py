@@ -12,6 +12,9 @@ from ultrazoom_amd import MewZoom
 from ultrazoom_amd.synth import synth_image, synth_state_dict
 
 VARIANTS = {"base": {"MZ_NO_Q": "1"}, "q": {}}
+if os.environ.get("LAYER_BENCH_VARIANTS"):   # e.g. LAYER_BENCH_VARIANTS='{"a": {}, "b": {"MZ_NO_Q": "1"}}'
+    import json
+    VARIANTS = json.loads(os.environ["LAYER_BENCH_VARIANTS"])
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 workload = sys.argv[2] if len(sys.argv) > 2 else "cfg3"
 if workload == "cfg2":
@@ -48,8 +51,9 @@ for r in range(rounds):
             acc[name][k].append(v)
         tot[name].append(t)
         os.unlink(path)
-keys = list(acc["base"].keys())
-print(f"{'layer':40s}" + "".join(f"{n:>12s}" for n in VARIANTS) + "   ratio(last/base)")
+first = next(iter(VARIANTS))
+keys = list(acc[first].keys())
+print(f"{'layer':40s}" + "".join(f"{n:>12s}" for n in VARIANTS) + "   ratio(last/first)")
 for k in keys:
     vals = [min(acc[n][k]) for n in VARIANTS]
     print(f"{' '.join(k):40s}" + "".join(f"{v:12.3f}" for v in vals) + f"   {vals[-1] / vals[0]:.3f}")

@@ -139,8 +139,9 @@ __device__ __forceinline__ void groups(f32x4 (&acc)[NPF][NF], Frag& f, const Bas
         groups<TT, G + 1, GE, XP, ZERO_T>(acc, f, bs);
     }
 }
-// accumulators of one pixel fragment -> plane-major tensor.  Lane (g, c) holds channels 4g..4g+3 of pixel c of each 16-channel
-// fragment; v_permlane16_swap between the two fragments of a pair leaves lane g with one full 16-byte plane entry.
+// accumulators of one pixel fragment -> plane-major tensor (entry16(), mz_device.h).  EPI_STORE: the lane's entry of channel-fragment
+// pair n lies at plane (nbase / 8 + 4 n + lane_cu), lane_cu = 2 (g & 1) + (g >> 1): one 64-bit base per pixel fragment, then a
+// uniform stride of four planes per pair.
 template <class TT, int EPI, bool SILU>
 __device__ __forceinline__ void store_pf(const ConvArgs& a, f32x4 (&accpf)[NF], int lane, int nbase, int b, int py, int px) {
     constexpr bool d2s = EPI == EPI_D2S;
@@ -148,36 +149,28 @@ __device__ __forceinline__ void store_pf(const ConvArgs& a, f32x4 (&accpf)[NF], 
     const long long plane_o = d2s ? (long long)a.Hout * a.Wout * 16 : (long long)a.H * a.W * 16;
     char* const obase = (char*)a.out + (long long)b * a.p_out * plane_o;
     const bool inside = py < a.H && px < a.W;
+    const int lane_cu = 2 * (g & 1) + (g >> 1);
+    if constexpr (!d2s) {
+        char* dst = obase + (long long)((nbase >> 3) + lane_cu) * plane_o + ((long long)py * a.W + px) * 16;
+        const long long stride = 4 * plane_o;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float ea = accpf[2 * n][j], eb = accpf[2 * n + 1][j];
-            const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, ea), __builtin_bit_cast(uint32_t, eb), false, false);
-            const uint32_t s0 = sw[0], s1 = sw[1];
-            v[j] = __builtin_bit_cast(float, s0);
-            v[4 + j] = __builtin_bit_cast(float, s1);
+        for (int n = 0; n < NT; ++n) {
+            const u32x4 o = entry16<TT, SILU>(accpf[2 * n], accpf[2 * n + 1]);
+            const int nch = nbase + (4 * n + lane_cu) * 8;
+            if (inside && nch < a.cp_out) *(u32x4*)dst = o;
+            dst += stride;
         }
-        const int cu = 2 * (2 * n + (g & 1)) + (g >> 1);  // 16-byte unit inside this workgroup's BN channels
-        const int nch = nbase + cu * 8;
-        if constexpr (SILU) {
+    } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = v[j] * sigmoidf_(v[j]);
-        }
-        if (!inside) continue;
-        char* dst;
-        if constexpr (d2s) {
-            if (nch >= 4 * a.cp_out) continue;
+        for (int n = 0; n < NT; ++n) {
+            const u32x4 o = entry16<TT, SILU>(accpf[2 * n], accpf[2 * n + 1]);
+            const int nch = nbase + (4 * n + lane_cu) * 8;
+            if (!inside || nch >= 4 * a.cp_out) continue;
             const int ij = nch / a.cp_out;
             const int ch = nch - ij * a.cp_out;
             const int Y = 2 * py + (ij >> 1), X = 2 * px + (ij & 1);
-            dst = obase + (ch >> 3) * plane_o + ((long long)Y * a.Wout + X) * 16;
-        } else {
-            if (nch >= a.cp_out) continue;
-            dst = obase + (nch >> 3) * plane_o + ((long long)py * a.W + px) * 16;
+            *(u32x4*)(obase + (ch >> 3) * plane_o + ((long long)Y * a.Wout + X) * 16) = o;
         }
-        st_unit<TT>(dst, v);
     }
 }
 

@@ -266,6 +266,40 @@ template <> __device__ __forceinline__ void mma16<TF16>(f32x4& acc, const u32x4&
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, w), __builtin_bit_cast(f16x8_t, x), acc, 0, 0, 0);
 }
 
+// ---- store epilogue of the 16x16x32 kernels: one 16-byte plane entry (8 channels) from a pair of accumulator fragments ----
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// SiLU of two values: the scale, the + 1 and the final product are packed-f32 instructions, the two transcendentals per value
+// stay scalar.  The same operations in the same order as v * sigmoidf_(v): identical bits.
+__device__ __forceinline__ f32x2 silu2(const f32x2 v) {
+    const f32x2 t = v * f32x2{-1.4426950408889634f, -1.4426950408889634f};
+    f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+    e = f32x2{1.0f, 1.0f} + e;
+    const f32x2 r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+    return v * r;
+}
+template <class TT> __device__ __forceinline__ uint32_t pack_pair(const f32x2 v) {
+    if constexpr (TT::IS_BF16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));  // v_cvt_pk_bf16_f32
+    else return pack_f16(v[0], v[1]);
+}
+// fa, fb: the two 16-channel accumulator fragments of a pair, lane (g, c) holding channels 4g..4g+3 of pixel c.  v_permlane16_swap
+// between them leaves lane row g with one whole plane entry of pixel c: fragment (g & 1), plane (g >> 1) of that fragment; fa then
+// holds channels 0..3 of the entry, fb channels 4..7.  IN PLACE (the accumulators are dead behind the epilogue: no register copies).
+template <class TT, bool SILU> __device__ __forceinline__ u32x4 entry16(f32x4& fa, f32x4& fb) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, (float)fa[j]), __builtin_bit_cast(uint32_t, (float)fb[j]), false, false);
+        const uint32_t s0 = sw[0], s1 = sw[1];
+        fa[j] = __builtin_bit_cast(float, s0);
+        fb[j] = __builtin_bit_cast(float, s1);
+    }
+    f32x2 p0 = {fa[0], fa[1]}, p1 = {fa[2], fa[3]}, p2 = {fb[0], fb[1]}, p3 = {fb[2], fb[3]};
+    if constexpr (SILU) { p0 = silu2(p0); p1 = silu2(p1); p2 = silu2(p2); p3 = silu2(p3); }
+    u32x4 o;
+    o[0] = pack_pair<TT>(p0); o[1] = pack_pair<TT>(p1); o[2] = pack_pair<TT>(p2); o[3] = pack_pair<TT>(p3);
+    return o;
+}
+
 // Tile index inside an image -> (tile row, tile column).  a.blk4 = 0: row-major.  a.blk4 = 1: block rows of FOUR tile rows walked
 // column by column, so that the ~32 workgroups that run on one XCD at a time (consecutive tile ids) cover a 4 x 8 block of tiles
 // instead of a 1 x 32 strip: the halo rows between vertically adjacent tiles are then shared through that XCD's L2 instead of

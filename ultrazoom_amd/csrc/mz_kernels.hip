@@ -1073,6 +1073,20 @@ __device__ __forceinline__ void store_frag16(const ConvArgs& a, f32x4 (&accpf)[2
     const int py = G::ROW_PER_WAVE == 2 ? y0 + 2 * w + (pf >> 1) : y0 + w;
     const int px = G::ROW_PER_WAVE == 2 ? x0 + 16 * (pf & 1) + c : x0 + 16 * pf + c;
     const bool inside = py < a.H && px < a.W;
+    const int lane_cu = 2 * (g & 1) + (g >> 1);  // 16-byte unit of the lane inside a channel-fragment pair's 4 planes
+    if constexpr (!d2s && !FILM) {
+        // one 64-bit base per pixel fragment, then a uniform stride of four planes per pair (entry16(): mz_device.h)
+        char* dst = obase + (long long)((nbase >> 3) + lane_cu) * plane_o + ((long long)py * a.W + px) * 16;
+        const long long stride = 4 * plane_o;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const u32x4 o = entry16<TT, SILU>(accpf[2 * n], accpf[2 * n + 1]);
+            const int nch = nbase + (4 * n + lane_cu) * 8;
+            if (inside && nch < a.cp_out) *(u32x4*)dst = o;
+            dst += stride;
+        }
+        return;
+    }
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         float v[8];
@@ -1085,8 +1099,7 @@ __device__ __forceinline__ void store_frag16(const ConvArgs& a, f32x4 (&accpf)[2
             v[j] = __builtin_bit_cast(float, s0);
             v[4 + j] = __builtin_bit_cast(float, s1);
         }
-        const int cu = 2 * (2 * n + (g & 1)) + (g >> 1);  // 16-byte unit inside this workgroup's BN channels
-        const int nch = nbase + cu * 8;
+        const int nch = nbase + (4 * n + lane_cu) * 8;
         if constexpr (SILU && !FILM) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = v[j] * sigmoidf_(v[j]);
