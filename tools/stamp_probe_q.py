@@ -13,12 +13,14 @@ for (B, H, W, cin, cout, silu) in [(3, 540, 960, 384, 192, 0), (3, 540, 960, 192
     x = torch.randn(B, cin // 8, H, W, 8, device="cuda").to(dt)
     w = torch.randn(cout, cin, 3, 3) * 0.02
     out = alloc_act(B, cout, H, W, dt)
-    for _ in range(3):
+    for _ in range(int(os.environ.get("REPS", "3"))):
         op_conv(dt, 0, x, None, w, 0.0, out, B, H, W, cin, cout, silu=silu)
     buf = (ctypes.c_ulonglong * (16 * 64 * 8))()
     assert _ffi.lib().mz_debug_read(buf) == 0
     a = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)
     for wv in range(4):
-        k, e, z, n = a[wv * 8: wv * 8 + 4]
+        k, e, z, n, cyc, rt = a[wv * 8: wv * 8 + 6]
         n = max(n, 1)
+        if wv == 0 and rt > 0:
+            print(f"   in-kernel clock of the last launch: {cyc / rt * 100.0:.0f} MHz (s_memtime / s_memrealtime x 100 MHz)")
         print(f"{H}x{W} {cin}->{cout} silu={silu} wave {wv}: tiles {n}, per tile: K loop {k // n} cycles, zeroing {z // n}, epilogue {e // n}  (epilogue share {100.0 * e / (k + e + z):.1f} %, ideal MFMA cycles per tile {cin // 32 * 324 * 16})")
