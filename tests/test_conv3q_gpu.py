@@ -48,8 +48,8 @@ def test_conv3q_matches_oracle_and_conv3s(dt, case, monkeypatch):
     x = q(rnd((B, cin, H, W), 21), dtype)
     w = q(wrnd((cout, cin, 3, 3), 22), dtype)
     outs = {}
-    for name, env in {"q": {}, "s": {"MZ_NO_Q": "1"}}.items():
-        for k in ("MZ_NO_Q", "MZ_PERSIST_WGS"):
+    for name, env in {"q": {"MZ_NO_R": "1"}, "s": {"MZ_NO_Q": "1", "MZ_NO_R": "1"}}.items():
+        for k in ("MZ_NO_Q", "MZ_NO_R", "MZ_PERSIST_WGS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -73,6 +73,7 @@ def test_conv3q_subpixel(dt, monkeypatch):
     x = q(rnd((B, cin, H, W), 23), dtype)
     w = q(wrnd((cout, cin, 3, 3), 24), dtype)
     monkeypatch.delenv("MZ_NO_Q", raising=False)
+    monkeypatch.setenv("MZ_NO_R", "1")
     monkeypatch.setenv("MZ_PERSIST_WGS", "8")
     out = alloc_act(B, cq, Hout, Wout, dtype)
     op_conv(dtype, 1, to_act(x, dtype), None, w, 0.0, out, B, H, W, cin, cout, Hout, Wout)

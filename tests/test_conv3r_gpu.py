@@ -1,0 +1,106 @@
+"""conv3r_kernel (conv3q's 8 x 48 x 96-channel tile with role-alternating waves: a tile's epilogue runs under the next tile's
+K loop) against the oracle and against conv3s_kernel.  All three 16x16x32 kernels accumulate every output element in the
+same order (chunk, tap, 32-channel MFMA), so they must agree bit for bit.  conv3r is the default where it applies (96-channel
+N tiles, >= 3 chunks of 32 channels -- odd counts included --, no more padded pixels than the conv3s tiles); MZ_NO_R=1 leaves
+conv3q (even chunk counts) / conv3s."""
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import DTYPES, alloc_act, assert_op_close, from_act, op_conv, pad_part, q, to_act
+from oracle import mewzoom_oracle as oracle
+from ultrazoom_amd.synth import hash_uniform
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(shape, seed, scale=1.0):
+    n = 1
+    for s in shape:
+        n *= s
+    return torch.from_numpy(((2.0 * hash_uniform(n, seed) - 1.0) * scale).reshape(shape))
+
+
+def wrnd(shape, seed):
+    fan_in = shape[1] * shape[2] * shape[3]
+    return rnd(shape, seed, (3.0 / fan_in) ** 0.5 * 1.7)
+
+
+R_CASES = [
+    # B, H, W, cin, cout, silu, persistent workgroups
+    (1, 8, 48, 96, 96, 0, 0),      # ONE tile: team X computes, team Y only loads; the final epilogue runs without a partner
+    (1, 8, 96, 96, 96, 1, 8),      # two tiles in one workgroup: one per team
+    (1, 16, 144, 96, 96, 1, 8),    # six tiles in one workgroup... (8 workgroups, 6 tiles: one each) -> see the next case
+    (3, 40, 100, 96, 192, 1, 8),   # 45 pixel tiles x 2 N tiles on 8 workgroups: ~11 tiles per workgroup, weight switches, odd counts
+    (2, 13, 37, 128, 96, 1, 0),    # ragged edges in both directions, four chunks
+    (1, 70, 70, 192, 96, 0, 8),    # six chunks
+    (1, 20, 130, 112, 96, 0, 8),   # Cin = 112: four chunks, the last one half zero planes
+    (2, 9, 250, 160, 288, 1, 16),  # five chunks, three N tiles
+    (1, 135, 240, 192, 96, 1, 0),  # the level-4 geometry of cfg3 (5 tiles per row, 17 tile rows)
+    (1, 24, 50, 96, 80, 1, 8),     # Cout = 80: the N tile's last plane pair does not exist (range-checked stores)
+    (1, 32, 96, 224, 96, 1, 8),    # seven chunks
+]
+
+
+def run(dtype, kind, x_act, w, out_shape, args, env, monkeypatch, wgs):
+    for k in ("MZ_NO_Q", "MZ_NO_R", "MZ_PERSIST_WGS"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    if wgs:
+        monkeypatch.setenv("MZ_PERSIST_WGS", str(wgs))
+    out = alloc_act(*out_shape, dtype)
+    op_conv(dtype, kind, x_act, None, w, 0.0, out, *args)
+    return out
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("case", R_CASES)
+def test_conv3r_matches_oracle_and_conv3s(dt, case, monkeypatch):
+    dtype = DTYPES[dt]
+    B, H, W, cin, cout, silu, wgs = case
+    x = q(rnd((B, cin, H, W), 31), dtype)
+    w = q(wrnd((cout, cin, 3, 3), 32), dtype)
+    xa = to_act(x, dtype)
+    outs = {}
+    for name, env in {"r": {}, "s": {"MZ_NO_Q": "1", "MZ_NO_R": "1"}}.items():
+        out = alloc_act(B, cout, H, W, dtype)
+        for k in ("MZ_NO_Q", "MZ_NO_R", "MZ_PERSIST_WGS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        if wgs:
+            monkeypatch.setenv("MZ_PERSIST_WGS", str(wgs))
+        op_conv(dtype, 0, xa, None, w, 0.0, out, B, H, W, cin, cout, silu=silu)
+        outs[name] = out
+    want = F.conv2d(x, w, padding=1)
+    if silu:
+        want = F.silu(want)
+    assert_op_close(from_act(outs["r"], cout), want, dt, "conv3r")
+    assert torch.equal(outs["r"], outs["s"]), "conv3r and conv3s must agree bit for bit"
+    assert (pad_part(outs["r"], cout) == 0).all(), "pad channels must stay zero"
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("shape", [(2, 40, 70, 96, 384, 81, 140), (1, 30, 100, 96, 192, 60, 200), (1, 16, 48, 128, 96, 33, 97)])
+def test_conv3r_subpixel(dt, shape, monkeypatch):
+    dtype = DTYPES[dt]
+    B, H, W, cin, cout, Hout, Wout = shape  # 96 -> 4 x 96 of the cfg3 head; 96 -> 4 x 48; 128 -> 4 x 24 (N tile spans all four sub-pixels)
+    cq = cout // 4
+    x = q(rnd((B, cin, H, W), 33), dtype)
+    w = q(wrnd((cout, cin, 3, 3), 34), dtype)
+    xa = to_act(x, dtype)
+    outs = {}
+    for name, env in {"r": {}, "s": {"MZ_NO_Q": "1", "MZ_NO_R": "1"}}.items():
+        for k in ("MZ_NO_Q", "MZ_NO_R"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        monkeypatch.setenv("MZ_PERSIST_WGS", "8")
+        out = alloc_act(B, cq, Hout, Wout, dtype)
+        op_conv(dtype, 1, xa, None, w, 0.0, out, B, H, W, cin, cout, Hout, Wout)
+        outs[name] = out
+    want = oracle.fit_to(oracle.subpixel_conv(x, w), (Hout, Wout))
+    assert_op_close(from_act(outs["r"], cq), want, dt, "conv3r d2s")
+    assert torch.equal(outs["r"], outs["s"]), "conv3r and conv3s must agree bit for bit (sub-pixel store)"

@@ -11,7 +11,7 @@ from bench import MODELS, parameter_shapes
 from ultrazoom_amd import MewZoom
 from ultrazoom_amd.synth import synth_image, synth_state_dict
 
-VARIANTS = {"base": {"MZ_NO_Q": "1"}, "q": {}}
+VARIANTS = {"base": {"MZ_NO_R": "1"}, "r": {}}
 if os.environ.get("LAYER_BENCH_VARIANTS"):   # e.g. LAYER_BENCH_VARIANTS='{"a": {}, "b": {"MZ_NO_Q": "1"}}'
     import json
     VARIANTS = json.loads(os.environ["LAYER_BENCH_VARIANTS"])
@@ -26,7 +26,7 @@ else:
 sd = synth_state_dict(parameter_shapes(cfg), seed=1234)
 models = {}
 for name, env in VARIANTS.items():
-    for k in ("MZ_Q", "MZ_NO_Q", "MZ_NO_BLK4", "MZ_KPAD_PCT"):
+    for k in ("MZ_Q", "MZ_NO_Q", "MZ_NO_R", "MZ_NO_BLK4", "MZ_KPAD_PCT"):
         os.environ.pop(k, None)
     os.environ.update(env)
     m = MewZoom(**cfg); m.load_state_dict(sd); m = m.to("cuda", torch.bfloat16).eval()

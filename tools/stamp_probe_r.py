@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Diagnostic: where the waves of conv3r_kernel spend their cycles (tools/build_variant.sh diag -DMZ_DIAG).
+MZ_DEBUG_STAMPS=1 MEWZOOM_HIP_LIB=$PWD/ultrazoom_amd/libmewzoom_hip_diag.so python tools/stamp_probe_r.py"""
+import ctypes, sys, os
+from pathlib import Path
+import numpy as np, torch
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent)); sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tests"))
+from gpu_util import alloc_act, op_conv
+from ultrazoom_amd import _ffi
+dt = torch.bfloat16
+CASES = [(3, 1080, 1920, 96, 192, 1), (3, 540, 960, 192, 384, 1), (3, 135, 240, 1536, 768, 0)]
+if os.environ.get("STAMP_CASES"): CASES = eval(os.environ["STAMP_CASES"])
+NAMES = {1: "plain step, chunk's first", 2: "plain step, later", 3: "epilogue step, chunk's first", 4: "epilogue step, later"}
+for (B, H, W, cin, cout, silu) in CASES:
+    x = torch.randn(B, cin // 8, H, W, 8, device="cuda").to(dt)
+    w = torch.randn(cout, cin, 3, 3) * 0.02
+    out = alloc_act(B, cout, H, W, dt)
+    for _ in range(int(os.environ.get("REPS", "3"))):
+        op_conv(dt, 0, x, None, w, 0.0, out, B, H, W, cin, cout, silu=silu)
+    buf = (ctypes.c_ulonglong * (16 * 64 * 8))()
+    assert _ffi.lib().mz_debug_read(buf) == 0
+    a = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)
+    print(f"== {H}x{W} {cin}->{cout} silu={silu}: ideal MFMA cycles per tile {cin // 32 * 324 * 16}, per step {cin // 32 * 324 * 16 // (2 * (cin // 32))}")
+    for wv in (0, 4):
+        r = a[wv * 32: wv * 32 + 32]
+        n = max(r[1], 1)
+        line = f"  wave {wv}: tiles {r[1]}, K loop {r[0] // n} cycles per tile, final epilogue {r[2]}"
+        print(line)
+        for c in (1, 2, 3, 4):
+            k = max(r[20 + c], 1)
+            print(f"      {NAMES[c]:30s} x{r[20 + c]:5d}: DMA issue {r[4 * c] // k:5d}  epilogue {r[4 * c + 1] // k:5d}  vmcnt wait {r[4 * c + 2] // k:5d}  barrier {r[4 * c + 3] // k:5d}")

@@ -1,0 +1,692 @@
+// conv3r_kernel ("relay"): 3x3 convolution (pad 1, stride 1) on v_mfma_f32_16x16x32_{bf16,f16} whose two waves per SIMD
+// ALTERNATE roles from tile to tile, so that a tile's store / SiLU / mix epilogue runs under the NEXT tile's K loop.
+//
+// Why (DESIGN.md section 5, round-2 stamps): in conv3q_kernel every SIMD holds one compute wave (96 px x 96 channels, 144
+// accumulator registers) and one loader wave whose 253 registers sit idle.  A tile of the Cin = 96 full-resolution layers is
+// only 3 - 6 K chunks long, and its epilogue (3.9 - 7.4 k cycles, store-path and SiLU bound) runs with the matrix pipe idle:
+// those layers reach 0.46 of the MFMA peak where the deep layers reach 0.65.
+//
+// Here the workgroup is two TEAMS of four waves (team X = waves 0..3, team Y = waves 4..7; waves w and w + 4 share a SIMD).
+// Tile i of the workgroup is computed by team i & 1.  While one team runs the K loop of tile i (exactly conv3q's compute
+// wave: same tile shape, same fragment stream, same summation order => bit-identical sums), the other team
+//   * issues all LDS-DMA of those half-steps (the loader role of conv3q: halo image one chunk ahead, weight segments two
+//     steps ahead -- near the end of the tile these already belong to tile i + 1),
+//   * finishes ITS OWN previous tile i - 1 out of its accumulators: SiLU / pack / stores, a few 16-byte entries per step,
+//     placed behind the step's DMA issue,
+//   * zeroes its accumulators and, in the tile's last step, primes its fragment registers for tile i + 1,
+// and at the tile boundary the teams swap.  The matrix pipe of a SIMD sees one uninterrupted K-loop stream; both register
+// files hold accumulators; a tile's K loop starts on a freshly primed wave, so odd chunk counts need no tap-parity carry.
+//
+// Stores and LDS-DMA share vmcnt (gfx9: loads, stores and LDS-DMA retire in issue order), so a step's stores are issued
+// BEHIND its DMA and the step ends with s_waitcnt vmcnt(#stores of this step): the DMA has landed, the stores may still be
+// in flight across the barrier.  For that count to be exact every store is a buffer_store whose out-of-image lanes carry
+// an out-of-range offset (dropped by the hardware's range check): the instruction is always issued.
+//
+// NSEG = weight segments (= barriers) per 32-channel chunk: 2 (14 + 13 groups, 3 x 28 KB weight slots, as conv3q) or 3
+// (9 + 9 + 9 groups = tap rows, 3 x 18 KB slots).  NSEG = 3 leaves 42 KB of LDS free: the fused variant (EPI_FUSEDMIX)
+// keeps the 36 KB of AdaptiveResidualMix gate weights resident there for the whole launch.
+//
+// LDS map: [halo 0 | halo 1] 2 x 32 KB + 3 weight slots (+ NSEG = 3, fused: 36 KB gate weights).
+#pragma once
+#include <type_traits>
+#include "mz_device.h"
+#include "mz_diag.h"
+
+namespace mz {
+namespace r3 {
+
+constexpr int TH = 8, TW = 48;
+constexpr int ROWW = 50;
+constexpr int NPIX = 10 * ROWW;      // 500 halo pixels
+constexpr int PLANE_ENT = 512;       // padded: 4 planes = 32 whole DMA instructions
+constexpr int A_PLANE = PLANE_ENT * 16;
+constexpr int A_SLOT = 4 * A_PLANE;  // 32 KB
+constexpr int NPF = 6;               // pixel fragments per wave: 2 rows x 3
+constexpr int NT = 3, NF = 6, BN = 96;
+constexpr int NG = 9 * NT;           // groups per 32-channel chunk
+constexpr int B_BASE = 2 * A_SLOT;
+constexpr int CHUNK_PIECES = 2 * NG; // 1-KiB pieces of a chunk's packed weights
+constexpr int MIX_PIECES = 4 * NT * NT;  // gate weights of the fused mix: 2 NT K-steps x NF fragments
+
+template <int NSEG> struct Seg {
+    static_assert(NSEG == 2 || NSEG == 3, "two or three weight segments per chunk");
+    static constexpr int start(int s) { return NSEG == 2 ? (s <= 0 ? 0 : (s == 1 ? (NG + 1) / 2 : NG)) : (NG / 3) * s; }
+    static constexpr int of(int G) { return NSEG == 2 ? (G < start(1) ? 0 : 1) : G / (NG / 3); }
+    static constexpr int pieces(int s) { return 2 * (start(s + 1) - start(s)); }
+    static constexpr int SLOT = pieces(0) * 1024;  // the largest segment is the first
+    static constexpr int AOFF_BASE = B_BASE + 3 * SLOT;  // 8 KB: halo offsets handed from team to team (4 waves x 8 pieces x 64 lanes)
+    static constexpr int MIX_BASE = AOFF_BASE + 8192;
+    static constexpr int lds_bytes(bool fuse) { return MIX_BASE + (fuse ? MIX_PIECES * 1024 : 0); }
+};
+
+// byte offset of pixel fragment pf of tap (dy, dx) inside one plane of the halo image, relative to the wave's first row
+template <int TAP, int PF> constexpr int a_off() {
+    constexpr int DY = TAP / 3, DX = TAP % 3;
+    return ((DY + PF / 3) * ROWW + DX + 16 * (PF % 3)) * 16;
+}
+
+struct Frag {
+    u32x4 x[2][NPF];  // [tap parity][pixel fragment]
+    u32x4 w[3][2];    // [group % 3][channel fragment of the pair]: requested TWO groups (24 MFMAs) ahead
+};
+
+template <int N> __device__ __forceinline__ void wait_w(u32x4& w0, u32x4& w1) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(w0), "+v"(w1) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_wx(u32x4& w0, u32x4& w1, u32x4& x0, u32x4& x1, u32x4& x2, u32x4& x3, u32x4& x4, u32x4& x5) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(w0), "+v"(w1), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5)
+                 : "n"(N)
+                 : "memory");
+}
+
+// LDS read addresses of one lane: halo image of the current / next chunk, weight slot of the current / next step
+struct Bases {
+    uint32_t a_cur, a_nxt, b_cur, b_nxt;
+};
+
+// Group GC of a chunk: tap t = GC / 3, channel-fragment pair n = GC % 3: 12 MFMAs.  While they issue, the wave requests the
+// weight pair of group GC + 2 and (n < 2) three pixel fragments of tap t + 1 -- from the NEXT slot / halo image where the
+// group or tap index runs past this segment / chunk.  Tap t reads pixel buffer (t + XP) & 1 (a chunk has 9 taps, so the
+// parity of a chunk's tap 0 flips from chunk to chunk; XP = chunk index & 1 inside the tile).
+template <class TT, int NSEG, int GC, int XP, int M>
+__device__ __forceinline__ void group_mfmas(f32x4 (&acc)[NPF][NF], Frag& f, const Bases& bs) {
+    if constexpr (M < 12) {
+        using S = Seg<NSEG>;
+        constexpr int t = GC / 3, n = GC % 3, xp = (t + XP) & 1, xq = xp ^ 1;
+        constexpr int sg = S::of(GC);
+        constexpr int Gs = S::start(sg), Ge = S::start(sg + 1);
+        constexpr int T = GC + 2;      // group whose weights are requested now
+        constexpr bool t_here = T < Ge;
+        constexpr int t_idx = t_here ? T - Gs : T - Ge;  // its index inside its segment
+        constexpr int k = M / 6, pf = M % 6;
+        mma16<TT>(acc[pf][2 * n + k], f.w[GC % 3][k], f.x[xp][pf]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (M < 2) {
+            f.w[T % 3][M] = lds_read128<(2 * t_idx + M) * 1024>(t_here ? bs.b_cur : bs.b_nxt);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (n < 2 && M >= 2 && M < 5) {
+            constexpr int pfn = 3 * n + (M - 2);
+            if constexpr (t + 1 < 9) f.x[xq][pfn] = lds_read128<a_off<t + 1, pfn>()>(bs.a_cur);
+            else f.x[xq][pfn] = lds_read128<a_off<0, pfn>()>(bs.a_nxt);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        group_mfmas<TT, NSEG, GC, XP, M + 1>(acc, f, bs);
+    }
+}
+
+// groups [G, GE) of one step
+template <class TT, int NSEG, int G, int GE, int XP>
+__device__ __forceinline__ void groups(f32x4 (&acc)[NPF][NF], Frag& f, const Bases& bs) {
+    if constexpr (G < GE) {
+        constexpr int t = G / 3, n = G % 3;
+        __builtin_amdgcn_sched_barrier(0);
+        group_mfmas<TT, NSEG, G, XP, 0>(acc, f, bs);
+        // what the NEXT group needs (also across the end of this step: the stream continues behind the barrier).  LDS reads
+        // return in order.  Reads requested per group: n = 0, 1: two weight + three pixel fragments, n = 2: two weight fragments.
+        constexpr int wn = (G + 1) % 3, xn = (t + 1 + XP) & 1;
+        if constexpr (n == 2)
+            wait_wx<2>(f.w[wn][0], f.w[wn][1], f.x[xn][0], f.x[xn][1], f.x[xn][2], f.x[xn][3], f.x[xn][4], f.x[xn][5]);
+        else if constexpr (n == 1)
+            wait_w<8>(f.w[wn][0], f.w[wn][1]);
+        else
+            wait_w<5>(f.w[wn][0], f.w[wn][1]);
+        groups<TT, NSEG, G + 1, GE, XP>(acc, f, bs);
+    }
+}
+
+// what the epilogue of a finished tile needs to know about it
+struct Done {
+    int mt, nt;
+};
+
+// gate GEMM of the fused mix (as conv3s_kernel<.., FUSE>): 2 NT K-steps of NF weight fragments, walked in half steps of NT
+// fragments; the next half step's fragments are requested before the current one's MFMAs are issued
+template <int H, int I> __device__ __forceinline__ void gate_reads(u32x4 (&wv)[NT], uint32_t addr) {
+    if constexpr (I < NT) {
+        constexpr int ks = H >> 1, part = H & 1;
+        wv[I] = lds_read128<(ks * 2 * NT + part * NT + I) * 1024>(addr);
+        gate_reads<H, I + 1>(wv, addr);
+    }
+}
+template <int N> __device__ __forceinline__ void gate_wait(u32x4 (&wv)[NT]) {
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]) : "n"(N) : "memory");
+}
+template <class TT, int H>
+__device__ __forceinline__ void gate_halves(f32x4 (&beta)[NF], const u32x4 (&xf)[NT], const u32x4 (&zf)[NT], u32x4 (&wa)[NT],
+                                            u32x4 (&wb)[NT], uint32_t addr) {
+    if constexpr (H < 4 * NT) {
+        constexpr int ks = H >> 1, part = H & 1;
+        constexpr bool more = H + 1 < 4 * NT;
+        if constexpr (more) gate_reads<H + 1, 0>(wb, addr);
+        gate_wait<(more ? NT : 0)>(wa);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            if constexpr (ks < NT) mma16<TT>(beta[part * NT + i], wa[i], xf[ks]);
+            else mma16<TT>(beta[part * NT + i], wa[i], zf[ks - NT]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        gate_halves<TT, H + 1>(beta, xf, zf, wb, wa, addr);
+    }
+}
+template <class TT> __device__ __forceinline__ void unpack2r(uint32_t v, float& lo, float& hi) {
+    if constexpr (TT::IS_BF16) {
+        lo = __builtin_bit_cast(float, v << 16);
+        hi = __builtin_bit_cast(float, v & 0xffff0000u);
+    } else {
+        lo = (float)__builtin_bit_cast(_Float16, (uint16_t)(v & 0xffff));
+        hi = (float)__builtin_bit_cast(_Float16, (uint16_t)(v >> 16));
+    }
+}
+template <class TT> __device__ __forceinline__ uint32_t pack2r(float lo, float hi) {
+    if constexpr (TT::IS_BF16) return pack_bf16(lo, hi);
+    else return pack_f16(lo, hi);
+}
+
+template <int V> using ic = std::integral_constant<int, V>;
+
+// v * sigmoid(v), one value: v_mul, v_exp, v_add, v_rcp, v_mul as inline asm (left to hipcc, the SLP vectoriser pairs the
+// multiplies and adds into v_pk_* again).  hipcc's hazard recogniser does not look inside inline asm: a VALU instruction that
+// reads the result of a transcendental one needs a wait state, hence the s_nop in front of the add and the final multiply.
+__device__ __forceinline__ float silu1(float v) {
+    float t, r;
+    asm("v_mul_f32 %0, 0xbfb8aa3b, %1" : "=v"(t) : "v"(v));
+    t = __builtin_amdgcn_exp2f(t);
+    asm("s_nop 0\n\tv_add_f32 %0, 1.0, %1" : "=v"(t) : "v"(t));
+    t = __builtin_amdgcn_rcpf(t);
+    asm("s_nop 0\n\tv_mul_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(t));
+    return r;
+}
+
+}  // namespace r3
+
+// EPI: EPI_STORE (runtime a.silu), EPI_D2S, EPI_FUSEDMIX (needs NSEG = 3).
+template <class TT, int NSEG, int EPI>
+__global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
+    using namespace r3;
+    using S = Seg<NSEG>;
+    constexpr bool FUSE = EPI == EPI_FUSEDMIX;
+    constexpr int B_SLOT = S::SLOT;
+    static_assert(!FUSE || NSEG == 3, "the gate weights need the LDS that three weight segments leave free");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int team = w >> 2, wq = w & 3;  // wq: SIMD = tile rows 2 wq, 2 wq + 1 (compute) = loader index
+    const int nchunks = a.nchunks16;       // 32-channel chunks, >= 3 (the host guards)
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+    // ---- tile walk (as conv3s_kernel: an XCD's contiguous id range, strided by the workgroups of that XCD) ----
+    const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3, step = gridDim.x >> 3;
+    const int q = a.grid >> 3, rem = a.grid & 7;
+    const int cnt = q + (xcd < rem ? 1 : 0);
+    const int base = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+    auto seek = [&](int i, int& mt, int& nt) __attribute__((always_inline)) {
+        while (i < cnt && !tile_of_s(a, base + i, mt, nt)) i += step;
+        return i;
+    };
+    // tA = the tile the workgroup is computing (or about to), tB = the one after it
+    int a_pos, a_mt = 0, a_nt = 0, b_pos, b_mt = 0, b_nt = 0;
+    a_pos = seek(pos, a_mt, a_nt);
+    if (a_pos >= cnt) return;  // uniform over the workgroup
+    b_pos = seek(a_pos + step, b_mt, b_nt);
+    auto advance = [&]() __attribute__((always_inline)) {
+        a_pos = b_pos; a_mt = b_mt; a_nt = b_nt;
+        if (a_pos < cnt) b_pos = seek(a_pos + step, b_mt, b_nt);
+    };
+
+    const int tpi = a.tiles_x * a.tiles_y;
+    auto tile_origin = [&](int mt, int& b, int& y0, int& x0) __attribute__((always_inline)) {
+        b = sdiv(mt, tpi, a.mg_tpi);
+        const int trem = mt - b * tpi;
+        int tyi, txi;
+        tile_rc_s(a, trem, tyi, txi);
+        y0 = tyi * TH;
+        x0 = txi * TW;
+    };
+
+    // slot counters of the step / chunk that is about to start: weights(h) live in slot hs = h % 3, halo(u) in slot us = u & 1
+    int hs = 0, us = 0;
+    auto next3 = [](int v) __attribute__((always_inline)) { return v == 2 ? 0 : v + 1; };
+
+    f32x4 acc[NPF][NF];
+    Frag f;
+    Done done = {0, 0};
+    RS_DECL;  // diagnostic builds: counters 0/1 = K-loop cycles / tiles; 4 c .. 4 c + 3 = DMA issue / epilogue / vmcnt wait / barrier of loader
+              // step class c = 1 + 2 (epilogue step) + (not a chunk's first step), 20 + c = steps of the class
+
+    const size_t chunk_bytes = (size_t)CHUNK_PIECES * 1024;
+    const long long plane_in = (long long)a.H * a.W * 16;
+
+    // ------------------------------------------------------------------------------------------------
+    // loader role
+    // ------------------------------------------------------------------------------------------------
+    uint32_t aoff[8];            // halo DMA offsets of this wave's 8 pieces (pieces wq + 4 i) for the tile being loaded
+    const char* img_l = nullptr;
+    auto set_load_tile = [&](int mt) __attribute__((always_inline)) {
+        int b, y0, x0;
+        tile_origin(mt, b, y0, x0);
+        img_l = (const char*)a.in0 + (long long)b * a.p0 * plane_in;
+        int lane_ = lane;
+        asm volatile("" : "+v"(lane_));  // opaque: nothing below is hoisted across the K loop (whose registers are all taken)
+        // Tiles whose whole 10 x 50 halo (and the row of pad entries behind it) lies inside the image need no per-entry bounds
+        // test: entry offset = ((plane H + py) W + px) 16 + delta(tile).  (Pad entries p >= 500 are never read by the compute
+        // waves: whatever in-range bytes they fetch are harmless, and an out-of-range offset reads zeros.)
+        const bool interior = y0 >= 1 && x0 >= 1 && y0 + TH + 2 <= a.H && x0 + TW + 1 <= a.W;
+        const uint32_t delta = ((uint32_t)(y0 - 1) * (uint32_t)a.W + (uint32_t)(x0 - 1)) * 16u;
+        if (interior) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = 64 * (wq + 4 * i) + lane_;
+                const int plane = e >> 9, p = e & 511;
+                const int py = (p * 1311) >> 16, px = p - py * ROWW;  // p / 50 for p < 512
+                aoff[i] = (((uint32_t)plane * (uint32_t)a.H + (uint32_t)py) * (uint32_t)a.W + (uint32_t)px) * 16u + delta;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = 64 * (wq + 4 * i) + lane_;
+                const int plane = e >> 9, p = e & 511;
+                const int py = (p * 1311) >> 16, px = p - py * ROWW;
+                const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+                const bool ok = (p < NPIX) & (gy >= 0) & (gy < a.H) & (gx >= 0) & (gx < a.W);
+                aoff[i] = ok ? (((uint32_t)plane * (uint32_t)a.H + (uint32_t)py) * (uint32_t)a.W + (uint32_t)px) * 16u + delta
+                             : 0xffffffffu;  // beyond the descriptor: the hardware returns zeros
+            }
+        }
+    };
+    // LDS-DMA, one 1-KiB piece at a time (the pieces of a step are interleaved with epilogue arithmetic: an LDS-DMA instruction
+    // holds the issuing wave for ~50 cycles -- the CU's L1 -> LDS path --, which the VALU work between two pieces hides).
+    // halo piece i (0..7) of this wave: entries [64 (wq + 4 i), + 64) of the image
+    auto halo_piece = [&](auto i_tag, const __amdgpu_buffer_rsrc_t rsrc, char* dst) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_tag)::value;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + (wq + 4 * i) * 1024), 16,
+                                                 (int)aoff[i], 0, 0, 0);
+    };
+    auto halo_rsrc = [&](int kc) __attribute__((always_inline)) {
+        const int planes = a.p0 - 4 * kc < 4 ? a.p0 - 4 * kc : 4;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(img_l + 4LL * kc * plane_in), 0, (int)(uint32_t)(planes * plane_in), 0x00020000);
+    };
+    // weight piece j = wq + 4 i of a segment of `pieces` pieces (s0 = the segment in HBM: wave-uniform; dst = its slot)
+    auto wseg_piece = [&](auto i_tag, const char* s0, int pieces, char* dst) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_tag)::value;
+        const int j = wq + 4 * i;
+        int lane_ = lane;
+        asm volatile("" : "+v"(lane_));  // opaque: the per-lane 64-bit offsets are not hoisted out of the tile loop (and spilled)
+        const uint32_t lo = (uint32_t)lane_ * 16u;  // scalar base + 32-bit lane offset
+        if (j < pieces) glds16(s0 + (size_t)(lo + (uint32_t)j * 1024u), dst + j * 1024);
+    };
+    constexpr int WP = (S::pieces(0) + 3) / 4;  // weight pieces per wave and step, at most
+    auto wsrc_of = [&](int nt) __attribute__((always_inline)) {
+        return (const char*)a.wpk16 + (size_t)nt * nchunks * chunk_bytes;
+    };
+
+    // ---- epilogue of the finished tile `done`, one 16-byte entry (pixel fragment pf, channel-fragment pair n) at a time ----
+    // per tile and lane: pix = byte offset of the lane's pixel of fragment 0 inside a plane (D2S: of its 2 x 2 target block),
+    // eoff[n] = offset of the entry of pair n relative to pix, or 0xffffffff where the channel does not exist
+    __amdgpu_buffer_rsrc_t orsrc;
+    uint32_t e_pix = 0, eoff[NT] = {0, 0, 0};
+    int e_c = 0, e_y = 0;
+    auto epi_setup = [&]() __attribute__((always_inline)) {
+        int lane_ = lane;
+        asm volatile("" : "+v"(lane_));
+        const int g = lane_ >> 4, c = lane_ & 15;
+        const int lane_cu = 2 * (g & 1) + (g >> 1);  // 16-byte unit of the lane inside a channel-fragment pair's 4 planes (entry16())
+        int d_b, d_y0, d_x0;
+        tile_origin(done.mt, d_b, d_y0, d_x0);
+        const int d_nbase = done.nt * BN;
+        e_c = d_x0 + c;
+        e_y = d_y0 + 2 * wq;
+        if constexpr (EPI == EPI_D2S) {
+            const long long plane_o = (long long)a.Hout * a.Wout * 16;
+            orsrc = __builtin_amdgcn_make_buffer_rsrc((char*)a.out + (long long)d_b * a.p_out * plane_o, 0,
+                                                      (int)(uint32_t)(a.p_out * plane_o), 0x00020000);
+            e_pix = ((uint32_t)(2 * e_y) * (uint32_t)a.Wout + (uint32_t)(2 * e_c)) * 16u;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int nch = d_nbase + (4 * n + lane_cu) * 8;
+                const int ij = nch / a.cp_out, ch = nch - ij * a.cp_out;
+                eoff[n] = nch < 4 * a.cp_out
+                              ? (uint32_t)(ch >> 3) * (uint32_t)plane_o + ((uint32_t)(ij >> 1) * (uint32_t)a.Wout + (uint32_t)(ij & 1)) * 16u
+                              : 0xffffffffu;
+            }
+        } else {
+            const long long plane_o = (long long)a.H * a.W * 16;
+            const int p_first = d_nbase >> 3;
+            const int planes = a.p_out - p_first < 4 * NT ? a.p_out - p_first : 4 * NT;
+            orsrc = __builtin_amdgcn_make_buffer_rsrc((char*)a.out + ((long long)d_b * a.p_out + p_first) * plane_o, 0,
+                                                      (int)(uint32_t)(planes * plane_o), 0x00020000);
+            e_pix = ((uint32_t)e_y * (uint32_t)a.W + (uint32_t)e_c) * 16u;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) eoff[n] = (uint32_t)(4 * n + lane_cu) * (uint32_t)plane_o;  // planes that do not exist fall out of range
+        }
+    };
+    // entry E = 3 pf + n, worked on in four QUARTERS (accumulator register j of the pair's two fragments): v_permlane16_swap pairs
+    // the fragments' quads into the lane's 8 channels (as entry16(), mz_device.h), in place; SiLU in SCALAR f32 instructions: the
+    // same operations in the same order as silu2() (identical bits), but no packed-f32 arithmetic -- v_pk_mul_f32 / v_pk_add_f32
+    // issue 7 x slower while the SIMD's other wave streams MFMAs (tools/microbench/mb_coissue.hip: 40 cycles each against 9
+    // for v_mul_f32 and 16 for v_exp_f32 / v_rcp_f32)
+    auto epi_quarter = [&](auto e_tag, auto j_tag, u32x4& o) __attribute__((always_inline)) {
+        constexpr int E = decltype(e_tag)::value, j = decltype(j_tag)::value;
+        constexpr int pf = E / NT, n = E % NT;
+        f32x4& fa = acc[pf][2 * n];
+        f32x4& fb = acc[pf][2 * n + 1];
+        const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, (float)fa[j]), __builtin_bit_cast(uint32_t, (float)fb[j]), false, false);
+        const uint32_t s0 = sw[0], s1 = sw[1];
+        float va = __builtin_bit_cast(float, s0), vb = __builtin_bit_cast(float, s1);
+        if constexpr (EPI != EPI_D2S) {
+            if (a.silu) { va = silu1(va); vb = silu1(vb); }
+        }
+        fa[j] = va;
+        fb[j] = vb;
+        if constexpr (j & 1) {
+            o[j >> 1] = pack_pair<TT>(f32x2{fa[j - 1], fa[j]});
+            o[2 + (j >> 1)] = pack_pair<TT>(f32x2{fb[j - 1], fb[j]});
+        }
+    };
+    auto epi_store = [&](auto e_tag, const u32x4& o) __attribute__((always_inline)) {
+        constexpr int E = decltype(e_tag)::value;
+        constexpr int pf = E / NT, n = E % NT;
+        const bool inside = e_y + pf / 3 < a.H && e_c + 16 * (pf % 3) < a.W;
+        uint32_t off;
+        if constexpr (EPI == EPI_D2S) off = e_pix + (uint32_t)(2 * (pf / 3)) * (uint32_t)a.Wout * 16u + (uint32_t)(32 * (pf % 3)) * 16u + eoff[n];
+        else off = e_pix + (uint32_t)(pf / 3) * (uint32_t)a.W * 16u + (uint32_t)(16 * (pf % 3)) * 16u + eoff[n];
+        if (!inside || eoff[n] == 0xffffffffu) off = 0xffffffffu;
+        __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, (int)off, 0, 0);
+    };
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int pf = 0; pf < NPF; ++pf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) acc[pf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    // fragment stream of a tile's first groups: tap 0 of chunk 0 and the weight pairs of groups 0 and 1
+    auto prime = [&](int wslot, int aslot) __attribute__((always_inline)) {
+        int lane_ = lane;
+        asm volatile("" : "+v"(lane_));
+        const int g = lane_ >> 4, c = lane_ & 15;
+        const uint32_t ab = lds_base + aslot * A_SLOT + g * A_PLANE + ((2 * wq) * ROWW + c) * 16;
+        const uint32_t bb = lds_base + B_BASE + wslot * B_SLOT + lane_ * 16;
+        f.x[0][0] = lds_read128<a_off<0, 0>()>(ab);
+        f.x[0][1] = lds_read128<a_off<0, 1>()>(ab);
+        f.x[0][2] = lds_read128<a_off<0, 2>()>(ab);
+        f.x[0][3] = lds_read128<a_off<0, 3>()>(ab);
+        f.x[0][4] = lds_read128<a_off<0, 4>()>(ab);
+        f.x[0][5] = lds_read128<a_off<0, 5>()>(ab);
+        f.w[0][0] = lds_read128<0 * 1024>(bb);
+        f.w[0][1] = lds_read128<1 * 1024>(bb);
+        f.w[1][0] = lds_read128<2 * 1024>(bb);
+        f.w[1][1] = lds_read128<3 * 1024>(bb);
+        wait_wx<0>(f.w[0][0], f.w[0][1], f.x[0][0], f.x[0][1], f.x[0][2], f.x[0][3], f.x[0][4], f.x[0][5]);
+        wait_w<0>(f.w[1][0], f.w[1][1]);
+    };
+
+    // ---- halo offsets travel between the teams through LDS: the loader team works out aoff[] of the NEXT tile (tB) one step
+    //      before it requests that tile's first halo image, and leaves a copy for the other team, which becomes the loader of
+    //      tB's later chunks one tile on (it is in the compute role, without a free register, until then) ----
+    auto aoff_table = [&]() __attribute__((always_inline)) {
+        int lane_ = lane;
+        asm volatile("" : "+v"(lane_));
+        return (u32x4*)(smem + S::AOFF_BASE + wq * 2048 + lane_ * 16);
+    };
+    auto aoff_publish = [&]() __attribute__((always_inline)) {
+        u32x4* t = aoff_table();
+        t[0] = u32x4{aoff[0], aoff[1], aoff[2], aoff[3]};
+        t[64] = u32x4{aoff[4], aoff[5], aoff[6], aoff[7]};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // written before this wave reaches the step's barrier
+    };
+    auto aoff_fetch = [&](int mt) __attribute__((always_inline)) {
+        const u32x4* t = aoff_table();
+        const u32x4 lo4 = t[0], hi4 = t[64];
+        aoff[0] = lo4[0]; aoff[1] = lo4[1]; aoff[2] = lo4[2]; aoff[3] = lo4[3];
+        aoff[4] = hi4[0]; aoff[5] = hi4[1]; aoff[6] = hi4[2]; aoff[7] = hi4[3];
+        int b, y0, x0;
+        tile_origin(mt, b, y0, x0);
+        img_l = (const char*)a.in0 + (long long)b * a.p0 * plane_in;
+    };
+
+    // One step of the loader role while the partner team computes chunk k of tile tA.
+    //   ES = first of this step's entries of the finished tile's epilogue, EN = how many (0..3)
+    //   last: the tile's last chunk (its loads already belong to the next tile tB);  pre: the chunk before it
+    const char* wA = nullptr;
+    const char* wB = nullptr;
+    bool okB = false;
+    auto loader_step = [&](auto es_tag, auto en_tag, auto sg_tag, auto last_tag, int k) __attribute__((always_inline)) {
+        constexpr int ES = decltype(es_tag)::value, EN = decltype(en_tag)::value, sg = decltype(sg_tag)::value;
+        constexpr bool last = decltype(last_tag)::value != 0;
+        constexpr int rs_c = 1 + (EN > 0 ? 2 : 0) + (sg == 0 ? 0 : 1);
+        static_assert(EN <= 3, "three output registers");
+        RS_BEGIN();
+        // ---- this step's DMA: in a chunk's first step the next chunk's halo image (first: its data comes from HBM and takes
+        //      longest), then weight segment (k, sg) + 2 steps ----
+        if constexpr (sg == 0) {
+            if (!last || okB) {
+                const __amdgpu_buffer_rsrc_t h_rsrc = halo_rsrc(last ? 0 : k + 1);
+                char* const h_dst = smem + (us ^ 1) * A_SLOT;
+                halo_piece(ic<0>{}, h_rsrc, h_dst); halo_piece(ic<1>{}, h_rsrc, h_dst); halo_piece(ic<2>{}, h_rsrc, h_dst);
+                halo_piece(ic<3>{}, h_rsrc, h_dst); halo_piece(ic<4>{}, h_rsrc, h_dst); halo_piece(ic<5>{}, h_rsrc, h_dst);
+                halo_piece(ic<6>{}, h_rsrc, h_dst); halo_piece(ic<7>{}, h_rsrc, h_dst);
+            }
+        }
+        {
+            constexpr bool same = sg + 2 < NSEG;
+            constexpr int qs = same ? sg + 2 : sg + 2 - NSEG;
+            const char* wsrc;
+            bool w_ok = true;
+            if constexpr (same) wsrc = wA + (size_t)k * chunk_bytes;
+            else if constexpr (!last) wsrc = wA + (size_t)(k + 1) * chunk_bytes;
+            else { wsrc = wB; w_ok = okB; }
+            wsrc += (size_t)(2 * S::start(qs)) * 1024;
+            const int w_pieces = w_ok ? S::pieces(qs) : 0;
+            char* const w_dst = smem + B_BASE + (hs >= 1 ? hs - 1 : 2) * B_SLOT;  // slot (hs + 2) % 3
+            wseg_piece(ic<0>{}, wsrc, w_pieces, w_dst); wseg_piece(ic<1>{}, wsrc, w_pieces, w_dst); wseg_piece(ic<2>{}, wsrc, w_pieces, w_dst);
+            wseg_piece(ic<3>{}, wsrc, w_pieces, w_dst); wseg_piece(ic<4>{}, wsrc, w_pieces, w_dst);
+            if constexpr (WP > 5) wseg_piece(ic<5>{}, wsrc, w_pieces, w_dst);
+            if constexpr (WP > 6) wseg_piece(ic<6>{}, wsrc, w_pieces, w_dst);
+            static_assert(WP <= 7, "seven weight pieces per wave and step");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+        RS_LAP(4 * rs_c);
+        // ---- this step's share of the finished tile's epilogue, behind the DMA issue: the arithmetic runs while the loads are in
+        //      flight, the stores go out behind the step's last DMA piece (vmcnt: see the head of this file) ----
+        u32x4 o0, o1, o2;
+        if constexpr (EN > 0) { epi_quarter(ic<ES>{}, ic<0>{}, o0); epi_quarter(ic<ES>{}, ic<1>{}, o0); epi_quarter(ic<ES>{}, ic<2>{}, o0); epi_quarter(ic<ES>{}, ic<3>{}, o0); }
+        if constexpr (EN > 1) { epi_quarter(ic<ES + 1>{}, ic<0>{}, o1); epi_quarter(ic<ES + 1>{}, ic<1>{}, o1); epi_quarter(ic<ES + 1>{}, ic<2>{}, o1); epi_quarter(ic<ES + 1>{}, ic<3>{}, o1); }
+        if constexpr (EN > 2) { epi_quarter(ic<ES + 2>{}, ic<0>{}, o2); epi_quarter(ic<ES + 2>{}, ic<1>{}, o2); epi_quarter(ic<ES + 2>{}, ic<2>{}, o2); epi_quarter(ic<ES + 2>{}, ic<3>{}, o2); }
+        if constexpr (EN > 0) epi_store(ic<ES>{}, o0);
+        if constexpr (EN > 1) epi_store(ic<ES + 1>{}, o1);
+        if constexpr (EN > 2) epi_store(ic<ES + 2>{}, o2);
+        if constexpr (sg == NSEG - 1) {
+            if constexpr (last) {
+                // the epilogue is complete: clear the accumulators and prime the fragment stream for the next tile.  Unconditional
+                // on every path into the compute role, so that the fragment registers are DEAD throughout the loader role.
+                zero_acc();
+                prime(next3(hs), us ^ 1);
+            } else {
+                if (k + 2 == nchunks && okB) {  // the next step requests tB's first halo image
+                    set_load_tile(b_mt);
+                    aoff_publish();
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        RS_LAP(4 * rs_c + 1);
+        // the DMA has landed once at most this step's stores (issued behind it) are outstanding
+        wait_vmcnt<EN>();
+        RS_LAP(4 * rs_c + 2);
+        __builtin_amdgcn_s_barrier();
+        RS_LAP(4 * rs_c + 3);
+        RS_COUNT(20 + rs_c);
+        hs = next3(hs);
+    };
+    // chunk iteration k; E0 = its first entry, N0 / N1 = entries of its first / second step
+    auto loader_chunk = [&](auto e0_tag, auto n0_tag, auto n1_tag, auto last_tag, int k) __attribute__((always_inline)) {
+        constexpr int E0 = decltype(e0_tag)::value, N0 = decltype(n0_tag)::value, N1 = decltype(n1_tag)::value;
+        static_assert(NSEG == 2, "schedule of the plain variants");
+        loader_step(ic<E0>{}, ic<N0>{}, ic<0>{}, last_tag, k);
+        loader_step(ic<E0 + N0>{}, ic<N1>{}, ic<1>{}, last_tag, k);
+        us ^= 1;
+    };
+    auto plain_chunks = [&](int k0) __attribute__((always_inline)) {  // chunks k0 .. nchunks - 1 without epilogue work
+        for (int k = k0; k + 1 < nchunks; ++k) loader_chunk(ic<0>{}, ic<0>{}, ic<0>{}, ic<0>{}, k);
+        loader_chunk(ic<0>{}, ic<0>{}, ic<0>{}, ic<1>{}, nchunks - 1);
+    };
+    auto loader_phase = [&](auto epi_tag) __attribute__((always_inline)) {
+        constexpr bool DO_EPI = decltype(epi_tag)::value != 0;
+        wA = wsrc_of(a_nt);
+        okB = b_pos < cnt;
+        wB = wsrc_of(okB ? b_nt : a_nt);
+        if constexpr (DO_EPI) {
+            aoff_fetch(a_mt);
+            epi_setup();
+            // The 18 entries are spread over the tile's first six chunks where it has six (1 + 2 per chunk: the first step also
+            // carries the halo image), else over its first three (3 + 3).
+            if (nchunks >= 6) {
+                loader_chunk(ic<0>{}, ic<1>{}, ic<2>{}, ic<0>{}, 0);
+                loader_chunk(ic<3>{}, ic<1>{}, ic<2>{}, ic<0>{}, 1);
+                loader_chunk(ic<6>{}, ic<1>{}, ic<2>{}, ic<0>{}, 2);
+                loader_chunk(ic<9>{}, ic<1>{}, ic<2>{}, ic<0>{}, 3);
+                loader_chunk(ic<12>{}, ic<1>{}, ic<2>{}, ic<0>{}, 4);
+                if (nchunks == 6) {
+                    loader_chunk(ic<15>{}, ic<1>{}, ic<2>{}, ic<1>{}, 5);
+                } else {
+                    loader_chunk(ic<15>{}, ic<1>{}, ic<2>{}, ic<0>{}, 5);
+                    plain_chunks(6);
+                }
+            } else {
+                loader_chunk(ic<0>{}, ic<3>{}, ic<3>{}, ic<0>{}, 0);
+                loader_chunk(ic<6>{}, ic<3>{}, ic<3>{}, ic<0>{}, 1);
+                if (nchunks == 3) {
+                    loader_chunk(ic<12>{}, ic<3>{}, ic<3>{}, ic<1>{}, 2);
+                } else {
+                    loader_chunk(ic<12>{}, ic<3>{}, ic<3>{}, ic<0>{}, 2);
+                    plain_chunks(3);
+                }
+            }
+        } else {
+            plain_chunks(0);
+        }
+    };
+
+    // ------------------------------------------------------------------------------------------------
+    // compute role: the K loop of tile tA (conv3q_kernel's compute wave)
+    // ------------------------------------------------------------------------------------------------
+    auto compute_phase = [&]() __attribute__((always_inline)) {
+        int lane_ = lane;
+        asm volatile("" : "+v"(lane_));
+        const int g = lane_ >> 4, c = lane_ & 15;
+        const uint32_t a_lane = lds_base + g * A_PLANE + ((2 * wq) * ROWW + c) * 16;
+        Bases bs;
+        bs.a_cur = a_lane + us * A_SLOT;
+        bs.a_nxt = a_lane + (us ^ 1) * A_SLOT;
+        const uint32_t bl = lds_base + B_BASE + lane_ * 16;
+        uint32_t b0 = bl + hs * B_SLOT, b1 = bl + next3(hs) * B_SLOT, b2 = bl + next3(next3(hs)) * B_SLOT;
+        bs.b_cur = b0;
+        bs.b_nxt = b1;
+        auto step_tail = [&]() __attribute__((always_inline)) {  // barrier; rotate the weight slots: cur <- nxt <- nn <- cur
+            __builtin_amdgcn_s_barrier();
+            const uint32_t u_ = b0; b0 = b1; b1 = b2; b2 = u_;
+            bs.b_cur = b0; bs.b_nxt = b1;
+        };
+        auto chunk = [&](auto xp_tag) __attribute__((always_inline)) {
+            constexpr int XP = decltype(xp_tag)::value;
+            groups<TT, NSEG, S::start(0), S::start(1), XP>(acc, f, bs);
+            step_tail();
+            groups<TT, NSEG, S::start(1), S::start(2), XP>(acc, f, bs);
+            step_tail();
+            if constexpr (NSEG == 3) {
+                groups<TT, NSEG, S::start(2), S::start(3), XP>(acc, f, bs);
+                step_tail();
+            }
+            const uint32_t v_ = bs.a_cur; bs.a_cur = bs.a_nxt; bs.a_nxt = v_;
+        };
+        // The last groups of a tile request fragments of a "next chunk" this wave will not compute: they are waited for behind
+        // the loop (the registers are reused by the loader role).
+        // The tap-0 parity XP alternates from chunk to chunk; the loop leaves after either body (an odd chunk count ends behind
+        // the XP = 0 body).  Both exits see the accumulators in the registers the loop carries them in: no copies, no spills
+        // (a peeled chunk in front of or behind a pair loop made hipcc rename them at the junction).
+        RS_BEGIN();
+        int kc = 0;
+        for (;;) {
+            chunk(ic<0>{});
+            if (++kc >= nchunks) break;
+            chunk(ic<1>{});
+            if (++kc >= nchunks) break;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(f.x[0][0]), "+v"(f.x[0][1]), "+v"(f.x[0][2]), "+v"(f.x[0][3]), "+v"(f.x[0][4]), "+v"(f.x[0][5]),
+                       "+v"(f.x[1][0]), "+v"(f.x[1][1]), "+v"(f.x[1][2]), "+v"(f.x[1][3]), "+v"(f.x[1][4]), "+v"(f.x[1][5])
+                     :
+                     : "memory");
+        asm volatile("" : "+v"(f.w[0][0]), "+v"(f.w[0][1]), "+v"(f.w[1][0]), "+v"(f.w[1][1]), "+v"(f.w[2][0]), "+v"(f.w[2][1]));
+        RS_LAP(0);
+        RS_COUNT(1);
+        // slot counters after NSEG * nchunks steps
+        const int adv = (NSEG * nchunks) % 3;
+        hs = hs + adv >= 3 ? hs + adv - 3 : hs + adv;
+        us ^= nchunks & 1;
+        done = Done{a_mt, a_nt};
+    };
+    auto final_entry = [&](auto e_tag) __attribute__((always_inline)) {
+        u32x4 o;
+        epi_quarter(e_tag, ic<0>{}, o); epi_quarter(e_tag, ic<1>{}, o); epi_quarter(e_tag, ic<2>{}, o); epi_quarter(e_tag, ic<3>{}, o);
+        epi_store(e_tag, o);
+    };
+    auto final_epilogue = [&]() __attribute__((always_inline)) {
+        epi_setup();
+        final_entry(ic<0>{}); final_entry(ic<1>{}); final_entry(ic<2>{}); final_entry(ic<3>{}); final_entry(ic<4>{}); final_entry(ic<5>{});
+        final_entry(ic<6>{}); final_entry(ic<7>{}); final_entry(ic<8>{}); final_entry(ic<9>{}); final_entry(ic<10>{}); final_entry(ic<11>{});
+        final_entry(ic<12>{}); final_entry(ic<13>{}); final_entry(ic<14>{}); final_entry(ic<15>{}); final_entry(ic<16>{}); final_entry(ic<17>{});
+    };
+
+    // ------------------------------------------------------------------------------------------------
+    if (team == 1) {
+        // prologue: chunk 0 of the first tile (halo image + the first two weight segments), published by B_0
+        wA = wsrc_of(a_nt);
+        set_load_tile(a_mt);
+        {
+            const __amdgpu_buffer_rsrc_t r0 = halo_rsrc(0);
+            halo_piece(ic<0>{}, r0, smem); halo_piece(ic<1>{}, r0, smem); halo_piece(ic<2>{}, r0, smem); halo_piece(ic<3>{}, r0, smem);
+            halo_piece(ic<4>{}, r0, smem); halo_piece(ic<5>{}, r0, smem); halo_piece(ic<6>{}, r0, smem); halo_piece(ic<7>{}, r0, smem);
+            const char* s1 = wA + (size_t)(2 * S::start(1)) * 1024;
+            char* d0 = smem + B_BASE;
+            char* d1 = smem + B_BASE + B_SLOT;
+            wseg_piece(ic<0>{}, wA, S::pieces(0), d0); wseg_piece(ic<1>{}, wA, S::pieces(0), d0); wseg_piece(ic<2>{}, wA, S::pieces(0), d0);
+            wseg_piece(ic<3>{}, wA, S::pieces(0), d0); wseg_piece(ic<4>{}, wA, S::pieces(0), d0); wseg_piece(ic<5>{}, wA, S::pieces(0), d0);
+            wseg_piece(ic<6>{}, wA, S::pieces(0), d0);
+            wseg_piece(ic<0>{}, s1, S::pieces(1), d1); wseg_piece(ic<1>{}, s1, S::pieces(1), d1); wseg_piece(ic<2>{}, s1, S::pieces(1), d1);
+            wseg_piece(ic<3>{}, s1, S::pieces(1), d1); wseg_piece(ic<4>{}, s1, S::pieces(1), d1); wseg_piece(ic<5>{}, s1, S::pieces(1), d1);
+            wseg_piece(ic<6>{}, s1, S::pieces(1), d1);
+        }
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();  // B_0
+        zero_acc();
+        loader_phase(ic<0>{});
+        advance();
+        if (a_pos >= cnt) { RS_DUMP(); return; }
+    } else {
+        __builtin_amdgcn_s_barrier();  // B_0
+        zero_acc();
+        prime(0, 0);
+    }
+    for (;;) {
+        compute_phase();
+        advance();
+        if (a_pos >= cnt) {
+            RS_BEGIN();
+            final_epilogue();
+            RS_LAP(2);
+            RS_DUMP();
+            return;
+        }
+        loader_phase(ic<1>{});
+        advance();
+        if (a_pos >= cnt) { RS_DUMP(); return; }
+    }
+}
+
+}  // namespace mz

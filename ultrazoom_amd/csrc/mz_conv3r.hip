@@ -1,0 +1,41 @@
+// conv3r_kernel instantiations and launcher (the kernel: mz_conv3r.h).
+#include "mz_conv3r.h"
+
+#ifndef MZ_R_NSEG
+#define MZ_R_NSEG 2  // weight segments per chunk of the plain / sub-pixel variants (the fused variant always uses 3)
+#endif
+
+namespace mz {
+
+template <class TT, int NSEG, int EPI> static hipError_t r_launch(const ConvArgs& a, hipStream_t s) {
+    constexpr size_t lds = r3::Seg<NSEG>::lds_bytes(EPI == EPI_FUSEDMIX);
+    static bool ready[16] = {};  // per device ordinal: the dynamic-LDS limit of this instantiation has been raised
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+    if (!ready[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3r_kernel<TT, NSEG, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        ready[dev] = true;
+    }
+    hipLaunchKernelGGL((conv3r_kernel<TT, NSEG, EPI>), dim3(a.persist), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+template <class TT> static hipError_t r_epi(const ConvArgs& a, hipStream_t s) {
+    switch (a.epi) {
+        case EPI_STORE: return r_launch<TT, MZ_R_NSEG, EPI_STORE>(a, s);
+        case EPI_D2S: return r_launch<TT, MZ_R_NSEG, EPI_D2S>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// a.persist workgroups of 512 threads; a.tiles_x / tiles_y / mtiles describe 8 x 48 tiles; 96-channel N tiles; >= 3 chunks
+hipError_t launch_conv3r(int dtype, const ConvArgs& a, hipStream_t s) {
+    if (a.persist <= 0 || (a.persist & 7) || a.nchunks16 < 3) return hipErrorInvalidValue;
+    switch (dtype) {
+        case DT_BF16: return r_epi<TBF16>(a, s);
+        case DT_F16: return r_epi<TF16>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace mz

@@ -255,6 +255,39 @@ __device__ __forceinline__ bool tile_of(const ConvArgs& a, int L, int& mtile, in
     return mtile < a.mtiles && ntile < a.ntiles;
 }
 
+// ---- the same tile arithmetic on the SCALAR unit (conv3r_kernel: its VALU issue is what the epilogue under the partner's MFMA
+// stream is short of; SALU instructions issue at full rate beside MFMAs, tools/microbench/mb_coissue.hip) ----
+// x / d for wave-uniform 0 <= x < 2^31, magic = floor(2^32 / d) (0xffffffff for d = 1): the estimate is at most one too small
+__device__ __forceinline__ int sdiv(int x, int d, uint32_t magic) {
+    const uint32_t xs = (uint32_t)__builtin_amdgcn_readfirstlane(x);
+    uint32_t q = (uint32_t)(((unsigned long long)xs * (unsigned long long)magic) >> 32);  // s_mul_hi_u32
+    q += (xs - q * (uint32_t)d >= (uint32_t)d) ? 1u : 0u;
+    return (int)q;
+}
+__device__ __forceinline__ bool tile_of_s(const ConvArgs& a, int L, int& mtile, int& ntile) {
+    const int gsz = a.gm * a.gn;
+    const int group = sdiv(L, gsz, a.mg_gsz), within = L - group * gsz;
+    const int gi_n = sdiv(group, a.groups_m, a.mg_groups_m), gi_m = group - gi_n * a.groups_m;
+    const int mi = sdiv(within, a.gn, a.mg_gn), ni = within - mi * a.gn;
+    mtile = gi_m * a.gm + mi;
+    ntile = gi_n * a.gn + ni;
+    return mtile < a.mtiles && ntile < a.ntiles;
+}
+__device__ __forceinline__ void tile_rc_s(const ConvArgs& a, int trem, int& tyi, int& txi) {
+    if (!a.blk4) {
+        tyi = sdiv(trem, a.tiles_x, a.mg_tiles_x);
+        txi = trem - tyi * a.tiles_x;
+        return;
+    }
+    const int bsz = 4 * a.tiles_x;
+    const int br = sdiv(trem, bsz, a.mg_bsz);
+    const int rem = trem - br * bsz;
+    int rows = a.tiles_y - 4 * br;  // tile rows of this block row: 4, or 1..3 for the last one
+    rows = rows < 4 ? rows : 4;
+    txi = rows == 4 ? rem >> 2 : (rows == 3 ? (int)(((unsigned)rem * 43691u) >> 17) : (rows == 2 ? rem >> 1 : rem));
+    tyi = 4 * br + rem - txi * rows;
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -1,0 +1,34 @@
+// Diagnostic hooks (in-kernel cycle stamps).  The shipped build defines every hook as a no-op; -DMZ_DIAG builds
+// (tools/build_variant.sh diag -DMZ_DIAG) accumulate s_memtime differences per wave and dump them into ConvArgs::dbg
+// (MZ_DEBUG_STAMPS=1 allocates it; mz_debug_read() copies it out; tools/stamp_probe_r.py prints it).
+#pragma once
+#ifdef MZ_DIAG
+#define RS_DECL uint32_t rs_[32] = {}; uint32_t rs_t0 = 0, rs_t1 = 0
+#define RS_NOW(v)                                                                         \
+    do {                                                                                  \
+        unsigned long long t__;                                                           \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");       \
+        v = (uint32_t)t__;                                                                \
+    } while (0)
+#define RS_BEGIN() RS_NOW(rs_t0)
+// adds the cycles since the previous RS_BEGIN / RS_LAP to counter i, counts the event in counter j (j < 0: not counted)
+#define RS_LAP(i)                 \
+    do {                          \
+        RS_NOW(rs_t1);            \
+        rs_[i] += rs_t1 - rs_t0;  \
+        rs_t0 = rs_t1;            \
+    } while (0)
+#define RS_COUNT(i) do { rs_[i] += 1; } while (0)
+#define RS_DUMP()                                                                                              \
+    do {                                                                                                       \
+        if (a.dbg && blockIdx.x == gridDim.x / 2 && lane == 0) {                                               \
+            _Pragma("unroll") for (int i__ = 0; i__ < 32; ++i__) a.dbg[w * 32 + i__] = rs_[i__];              \
+        }                                                                                                      \
+    } while (0)
+#else
+#define RS_DECL do { } while (0)
+#define RS_BEGIN() do { } while (0)
+#define RS_LAP(i) do { } while (0)
+#define RS_COUNT(i) do { } while (0)
+#define RS_DUMP() do { } while (0)
+#endif

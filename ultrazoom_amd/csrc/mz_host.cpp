@@ -69,6 +69,7 @@ struct Knobs {
     int kpad_pct = 12;      // MZ_KPAD_PCT=n: the 16x16x32 kernels take Cin whose padding to whole 32-channel chunks is <= n %
     int blk4 = 1;           // MZ_NO_BLK4=1: row-major tile walk inside an image (A/B of the L2 sharing of vertical halos)
     int q = 1;              // MZ_NO_Q=1: never use conv3q_kernel (one compute + one loader wave per SIMD, 8 x 48 tiles)
+    int r = 1;              // MZ_NO_R=1: never use conv3r_kernel (conv3q's tile with role-alternating waves: epilogues under the next K loop)
 };
 static Knobs read_knobs() {
     Knobs k;
@@ -79,6 +80,7 @@ static Knobs read_knobs() {
     k.fuse16 = getenv("MZ_NO_FUSE16") == nullptr;
     k.mix16 = getenv("MZ_NO_MIX16") == nullptr;
     k.q = getenv("MZ_NO_Q") == nullptr;
+    k.r = getenv("MZ_NO_R") == nullptr;
     k.blk4 = getenv("MZ_NO_BLK4") == nullptr;
     if (const char* e = getenv("MZ_KPAD_PCT")) k.kpad_pct = atoi(e);
     if (getenv("MZ_NO_PERSIST") != nullptr) k.persist = 0;
@@ -647,6 +649,10 @@ struct Runner {
         a.inv_tiles_x = a.tiles_x > 0 ? 1.0f / (float)a.tiles_x : 1.0f;
         a.inv_bsz = a.tiles_x > 0 ? 1.0f / (float)(4 * a.tiles_x) : 1.0f;
         a.blk4 = knobs.blk4 && a.tiles_x > 0 && 4 * a.tiles_x < 65536 ? 1 : 0;  // read by conv3s_kernel / conv3q_kernel only
+        auto magic = [](long long d) { return d <= 1 ? 0xffffffffu : (uint32_t)(4294967296ULL / (unsigned long long)d); };
+        a.mg_gsz = magic((long long)a.gm * a.gn); a.mg_groups_m = magic(a.groups_m); a.mg_gn = magic(a.gn);
+        a.mg_tpi = magic(a.tiles_x > 0 ? (long long)a.tiles_x * a.tiles_y : 1); a.mg_tiles_x = magic(a.tiles_x > 0 ? a.tiles_x : 1);
+        a.mg_bsz = magic(a.tiles_x > 0 ? 4LL * a.tiles_x : 1);
     }
 
     // conv3x3, pad 1 (model.py:742-748, 900-909, 1010). epi: STORE / D2S / FINAL
@@ -697,14 +703,19 @@ struct Runner {
         // conv3q_kernel: one 512-register wave per SIMD, 8 x 48 pixel tiles, 96-channel N tiles
         // (measured on the cfg3 shapes, tools/layer_bench.py: equal to conv3s_kernel where both tile shapes fit the image, 8 - 12 %
         // faster on the 240-pixel-wide level, whose rows 48-pixel tiles cover exactly; it takes even chunk counts only)
-        bool use_q = knobs.q && use_s16 && !film_gamma && dtype != DT_F32 && c.nt == 3 && c.packed16 && (epi == EPI_STORE || epi == EPI_D2S) &&
-                     persist_wgs > 0 && c.nchunks16 % 2 == 0 && c.nchunks16 * 32 * 100 <= c.cp0 * (100 + knobs.kpad_pct) &&
-                     (double)H * W * 64.0 < 4294967296.0;
-        if (use_q) {  // padded pixels of its 8 x 48 tiles against the better of the 8 x 64 / 16 x 32 tiles
+        bool q_common = use_s16 && !film_gamma && dtype != DT_F32 && c.nt == 3 && c.packed16 && (epi == EPI_STORE || epi == EPI_D2S) &&
+                        persist_wgs > 0 && c.nchunks16 * 32 * 100 <= c.cp0 * (100 + knobs.kpad_pct) &&
+                        (double)H * W * 64.0 < 4294967296.0;
+        if (q_common) {  // padded pixels of the 8 x 48 tiles against the better of the 8 x 64 / 16 x 32 tiles
             const long long padq = (long long)((H + 7) / 8 * 8) * ((W + 47) / 48 * 48);
             const long long pads = (long long)a.tiles_y * th * a.tiles_x * tw;
-            use_q = padq <= pads;
+            q_common = padq <= pads;
         }
+        // conv3r_kernel: any chunk count >= 3; its stores carry 32-bit offsets inside 12 output planes / one D2S target image
+        const bool use_r = knobs.r && q_common && c.nchunks16 >= 3 &&
+                           (epi == EPI_D2S ? (double)(c.cq_p * dtype_size(dtype) / 16) * Hout * Wout * 16.0 < 4294967296.0
+                                           : 12.0 * H * W * 16.0 < 4294967296.0);
+        const bool use_q = use_r || (knobs.q && q_common && c.nchunks16 % 2 == 0);
         if (use_q) {
             a.tiles_x = (W + 47) / 48; a.tiles_y = (H + 7) / 8;
             a.mtiles = B * a.tiles_x * a.tiles_y;
@@ -715,7 +726,8 @@ struct Runner {
             ProfRec* r;
             prof_begin(r, 2.0 * px * 9.0 * c.cin * c.cout, px * (c.cin + c.cout) * sz + 9.0 * c.cin * c.cout * sz, 1);
             if (r) { r->kind = 0; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.gm * 1000 + a.gn; }
-            check(launch_conv3q(dtype, a, s), "conv3q launch");
+            if (use_r) check(launch_conv3r(dtype, a, s), "conv3r launch");
+            else check(launch_conv3q(dtype, a, s), "conv3q launch");
             prof_end(r);
             return;
         }

@@ -57,6 +57,8 @@ struct ConvArgs {
     float inv_gsz, inv_groups_m, inv_gn, inv_tpi, inv_tiles_x;  // 1.0f / divisor for fdiv() (all dividends < 2^24)
     int blk4;          // conv3s / conv3q: tiles of an image are walked in block rows of four tile rows (tile_rc(), mz_device.h)
     float inv_bsz;     // 1.0f / (4 * tiles_x)
+    // conv3r_kernel: the same divisors as floor(2^32 / d) for sdiv() (scalar-unit division, mz_device.h)
+    uint32_t mg_gsz, mg_groups_m, mg_gn, mg_tpi, mg_tiles_x, mg_bsz;
     int epi;
     int silu;
     int cp_out;        // STORE/MIX: padded channels of out; D2S: channels per output pixel (cq_p)
@@ -89,6 +91,10 @@ hipError_t init_kernels();  // raises the dynamic-LDS limits (per device)
 // 512-register wave per SIMD.  a.persist workgroups of 256 threads; a.wpk16 / a.nchunks16 as for conv3s_kernel.
 hipError_t launch_conv3q(int dtype, const ConvArgs& a, hipStream_t s);
 hipError_t init_conv3q();
+// conv3r_kernel (mz_conv3r.h): the same tile shape and K loop, but the two waves of every SIMD alternate between the compute
+// and the loader + epilogue role from tile to tile.  >= 3 chunks of 32 channels (odd counts included); EPI_STORE / EPI_D2S
+// (32-bit store offsets: 12 planes of the output, resp. one whole D2S target image, must stay below 4 GiB).
+hipError_t launch_conv3r(int dtype, const ConvArgs& a, hipStream_t s);
 
 // ---- weight packing ---------------------------------------------------------------------------
 enum OutMap : int { OUT_PLAIN = 0, OUT_D2S = 1, OUT_FINAL = 2 };
