@@ -133,6 +133,12 @@ int mz_op_stem(int dtype, const void* x, const float* w_dev_f32, const float* b_
 int mz_op_final(int dtype, const void* feat, const void* img, const float* w_dev_f32, void* out, int B, int H,
                 int W, int cin, int R, int clamp, void* hip_stream);
 
+/* conv2 of an Encoder/DecoderBlock + AdaptiveResidualMix with the block input, ONE launch (reference model.py:773-778 second half and
+ * 826-839: z = conv3x3(hid, w2); out = x + sigmoid(alpha) sigmoid(Wmix [x ; z]) (z - x)): the fused kernels of C <= 96.
+ * hid [B,H,W,cin_p]; x, out [B,H,W,cout_p]; w2 [cout,cin,3,3]; wmix [cout,2 cout,1,1] (float32 on the device) */
+int mz_op_conv_mix(int dtype, const void* hid, const void* x, const float* w2_dev_f32, const float* wmix_dev_f32, float alpha,
+                   void* out, int B, int H, int W, int cin, int cout, void* hip_stream);
+
 /* a17 of SURVEY.md section 8 -- NO reference counterpart: the snapshot (v0.3.0) has no ControlModule / FiLM (README.md:86-129
  * describes library version 0.2.x, whose source is absent), so this operator is "parity unpinned": it is checked against the
  * build's own CPU restatement (oracle.film_conv) only.   out = act(gamma[b, c] * conv3x3(in0, w)[b, c] + beta[b, c]),

@@ -32,6 +32,14 @@ def op_excess(got: torch.Tensor, want: torch.Tensor, dt: str) -> float:
     return (diff / (ulp_of(want, dt) + 1e-5)).max().item()
 
 
+def op_excess_map(got: torch.Tensor, want: torch.Tensor, dt: str) -> torch.Tensor:
+    """|got - want| / tolerance(element), element-wise."""
+    diff = (got.float() - want.float()).abs()
+    if dt == "f32":
+        return diff / F32_OP_TOL
+    return diff / (ulp_of(want, dt) + 1e-5)
+
+
 def assert_op_close(got: torch.Tensor, want: torch.Tensor, dt: str, what: str = "") -> float:
     ex = op_excess(got, want, dt)
     worst = (got.float() - want.float()).abs().max().item()

@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from gpu_util import DTYPES, alloc_act, assert_op_close, from_act, op_conv, pad_part, q, to_act
+from gpu_util import DTYPES, alloc_act, assert_op_close, from_act, op_conv, op_excess, op_excess_map, pad_part, q, to_act
 from oracle import mewzoom_oracle as oracle
 from ultrazoom_amd.synth import hash_uniform
 
@@ -104,3 +104,72 @@ def test_conv3r_subpixel(dt, shape, monkeypatch):
     want = oracle.fit_to(oracle.subpixel_conv(x, w), (Hout, Wout))
     assert_op_close(from_act(outs["r"], cq), want, dt, "conv3r d2s")
     assert torch.equal(outs["r"], outs["s"]), "conv3r and conv3s must agree bit for bit (sub-pixel store)"
+
+
+# ---- fused conv2 + AdaptiveResidualMix (model.py:773-778, 826-839) on conv3r_kernel: one pixel fragment's gate GEMM + blend per chunk
+#      under the partner's K loop; identical bits to conv3s_kernel<.., FUSE> ----
+def op_conv_mix(dtype, hid, x, w2, wmix, alpha, out, B, H, W, cin, cout):
+    import ctypes
+    from ultrazoom_amd import _ffi
+    from gpu_util import stream_ptr
+    w2d = w2.to("cuda", torch.float32).contiguous()
+    wmd = wmix.to("cuda", torch.float32).contiguous()
+    _ffi.check(_ffi.lib().mz_op_conv_mix(
+        _ffi.dtype_code(dtype), ctypes.c_void_p(hid.data_ptr()), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(w2d.data_ptr()),
+        ctypes.c_void_p(wmd.data_ptr()), ctypes.c_float(alpha), ctypes.c_void_p(out.data_ptr()), B, H, W, cin, cout,
+        ctypes.c_void_p(stream_ptr())))
+    torch.cuda.synchronize()
+
+
+FUSE_CASES = [
+    # B, H, W, cin, cout, persistent workgroups
+    (1, 8, 48, 192, 96, 0),      # one tile: the final epilogue without a partner
+    (1, 16, 144, 192, 96, 8),    # one tile per workgroup
+    (3, 40, 100, 192, 96, 8),    # ~6 tiles per workgroup, ragged edges
+    (2, 13, 37, 192, 96, 0),
+    (1, 70, 70, 224, 96, 8),     # seven chunks: a plain chunk behind the six epilogue chunks
+    (1, 24, 50, 384, 96, 8),     # hidden_ratio 4: twelve chunks
+    (1, 24, 50, 160, 80, 8),     # C = 80: five chunks -> the host keeps conv3s_kernel; both settings must still agree
+    (1, 20, 60, 192, 88, 8),     # C = 88: pad channels in x, z and out
+]
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("case", FUSE_CASES)
+def test_conv3r_fused_mix(dt, case, monkeypatch):
+    dtype = DTYPES[dt]
+    B, H, W, cin, cout, wgs = case
+    hid = q(rnd((B, cin, H, W), 41), dtype)
+    x = q(rnd((B, cout, H, W), 42), dtype)
+    w2 = q(wrnd((cout, cin, 3, 3), 43), dtype)
+    wmix = q(rnd((cout, 2 * cout, 1, 1), 44, (3.0 / (2 * cout)) ** 0.5 * 1.7), dtype)
+    alpha = 0.3
+    ha, xa = to_act(hid, dtype), to_act(x, dtype)
+    outs = {}
+    for name, env in {"r": {}, "s": {"MZ_NO_R": "1"}}.items():
+        for k in ("MZ_NO_R", "MZ_PERSIST_WGS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        if wgs:
+            monkeypatch.setenv("MZ_PERSIST_WGS", str(wgs))
+        out = alloc_act(B, cout, H, W, dtype)
+        op_conv_mix(dtype, ha, xa, w2, wmix, alpha, out, B, H, W, cin, cout)
+        outs[name] = out
+    # the kernel rounds z to the storage type before the gate GEMM and the blend (as the unfused path stores it)
+    z = q(F.conv2d(hid, w2, padding=1), dtype)
+    want = oracle.residual_mix(x, z, wmix, torch.tensor(alpha))
+    got = from_act(outs["r"], cout)
+    # one rounding of the output, plus one rounding step of z where its fp32 sum sits on a rounding boundary (the blend passes
+    # sigmoid(alpha) * beta <= 1 of it on): element-wise |got - want| <= ulp(want) + ulp(z) + 1e-5
+    from gpu_util import ulp_of
+    tol = ulp_of(want, dt) + ulp_of(z, dt) + 1e-5
+    ex = ((got - want).abs() / tol).max().item()
+    assert ex <= 1.0, f"fused conv2 + mix {dt}: {ex:.2f} x (ulp(out) + ulp(z) + 1e-5)"
+    assert ((got - want).abs() > ulp_of(want, dt) + 1e-5).float().mean().item() < 0.02, "more than 2 % of the outputs are off by more than one ulp"
+    # conv3s_kernel<.., FUSE> sums the same gate products in another order inside each 32-wide K step (its x half is packed in plane
+    # order): equal up to the last bit of the output, and equal bit for bit nearly everywhere
+    b_ = from_act(outs["s"], cout)
+    assert (got == b_).float().mean().item() > 0.98, "conv3r and conv3s fused kernels: more than 2 % of the outputs differ"
+    assert ((got - b_).abs() / tol).max().item() <= 1.0, "conv3r and conv3s fused kernels differ by more than the tolerance"
+    assert (pad_part(outs["r"], cout) == 0).all(), "pad channels must stay zero"

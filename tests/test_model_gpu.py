@@ -334,9 +334,9 @@ def test_kernel_variants_agree(dtype, monkeypatch):
     m = build(case, sd, dtype)
     xg = x.to("cuda", dtype)
     outs = {}
-    for name, env in {"default": {}, "no_fuse16": {"MZ_NO_FUSE16": "1"}, "no_fuse": {"MZ_NO_FUSE": "1"},
+    for name, env in {"default": {}, "no_fuse16": {"MZ_NO_FUSE16": "1"}, "no_fuse": {"MZ_NO_FUSE": "1"}, "no_r": {"MZ_NO_R": "1"},
                       "no_s16": {"MZ_NO_S16": "1"}, "no_persist": {"MZ_NO_PERSIST": "1"}, "no_wide": {"MZ_NO_WIDE": "1"}}.items():
-        for k in ("MZ_NO_FUSE16", "MZ_NO_FUSE", "MZ_NO_S16", "MZ_NO_PERSIST", "MZ_NO_WIDE"):
+        for k in ("MZ_NO_FUSE16", "MZ_NO_FUSE", "MZ_NO_S16", "MZ_NO_PERSIST", "MZ_NO_WIDE", "MZ_NO_R"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -354,8 +354,9 @@ def test_kernel_variants_agree(dtype, monkeypatch):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_conv3q_and_tile_walk_knobs_leave_the_bits_unchanged(dtype, monkeypatch):
-    """conv3q_kernel and conv3s_kernel accumulate in the same order, and the block-row tile walk only changes which workgroup
-    computes which tile: a model whose deep levels run conv3q must produce the SAME BITS with MZ_NO_Q=1 and with MZ_NO_BLK4=1
+    """conv3r_kernel, conv3q_kernel and conv3s_kernel accumulate in the same order, and the block-row tile walk only changes which
+    workgroup computes which tile: a model whose deep levels run conv3r must produce the SAME BITS with MZ_NO_R=1 (conv3q / conv3s),
+    with MZ_NO_Q=1 MZ_NO_R=1 (conv3s everywhere) and with MZ_NO_BLK4=1
     (knobs are read when the engine is created, hence refresh_weights())."""
     names = ("primary", "secondary", "tertiary", "quaternary")
     cfg = {"upscale_ratio": 2, "hidden_ratio": 2, "num_deg_features": 3}
@@ -366,8 +367,9 @@ def test_conv3q_and_tile_walk_knobs_leave_the_bits_unchanged(dtype, monkeypatch)
     x = synth_image(3, 200, 392, seed=6).to("cuda", dtype)   # levels 3 / 4 at 50 x 98 and 25 x 49: several ragged 8 x 48 tiles
     m = build(cfg, sd, dtype)
     outs = {}
-    for name, env in {"default": {}, "no_q": {"MZ_NO_Q": "1"}, "no_blk4": {"MZ_NO_BLK4": "1"}, "few_wgs": {"MZ_PERSIST_WGS": "8"}}.items():
-        for k in ("MZ_NO_Q", "MZ_NO_BLK4", "MZ_PERSIST_WGS"):
+    for name, env in {"default": {}, "no_r": {"MZ_NO_R": "1"}, "no_q_no_r": {"MZ_NO_Q": "1", "MZ_NO_R": "1"}, "no_blk4": {"MZ_NO_BLK4": "1"},
+                      "few_wgs": {"MZ_PERSIST_WGS": "8"}, "few_wgs_no_r": {"MZ_PERSIST_WGS": "8", "MZ_NO_R": "1"}}.items():
+        for k in ("MZ_NO_Q", "MZ_NO_R", "MZ_NO_BLK4", "MZ_PERSIST_WGS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -61,6 +61,8 @@ def _declare(lib) -> None:
     lib.mz_op_conv.argtypes = [c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p] + [c_int] * 8 + [c_void_p]
     lib.mz_op_conv_film.argtypes = [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]
     lib.mz_op_conv_film.restype = c_int
+    lib.mz_op_conv_mix.argtypes = [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p] + [c_int] * 5 + [c_void_p]
+    lib.mz_op_conv_mix.restype = c_int
     lib.mz_op_stem.argtypes = [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     lib.mz_op_final.argtypes = [c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]
     lib.mz_last_error.restype = c_char_p

@@ -54,9 +54,9 @@ template <int NSEG> struct Seg {
     static constexpr int of(int G) { return NSEG == 2 ? (G < start(1) ? 0 : 1) : G / (NG / 3); }
     static constexpr int pieces(int s) { return 2 * (start(s + 1) - start(s)); }
     static constexpr int SLOT = pieces(0) * 1024;  // the largest segment is the first
-    static constexpr int AOFF_BASE = B_BASE + 3 * SLOT;  // 8 KB: halo offsets handed from team to team (4 waves x 8 pieces x 64 lanes)
-    static constexpr int MIX_BASE = AOFF_BASE + 8192;
-    static constexpr int lds_bytes(bool fuse) { return MIX_BASE + (fuse ? MIX_PIECES * 1024 : 0); }
+    static constexpr int AOFF_BASE = B_BASE + 3 * SLOT;  // plain variants, 8 KB: halo offsets handed from team to team (4 waves x 8 pieces x 64 lanes)
+    static constexpr int MIX_BASE = B_BASE + 3 * SLOT;   // fused variant, 36 KB: the gate weights (instead of the hand-off table)
+    static constexpr int lds_bytes(bool fuse) { return fuse ? MIX_BASE + MIX_PIECES * 1024 : AOFF_BASE + 8192; }
 };
 
 // byte offset of pixel fragment pf of tap (dy, dx) inside one plane of the halo image, relative to the wave's first row
@@ -188,6 +188,14 @@ template <class TT> __device__ __forceinline__ uint32_t pack2r(float lo, float h
 
 template <int V> using ic = std::integral_constant<int, V>;
 
+// lane index, recomputed where it is needed (v_mbcnt): no register holds it across the K loop, whose 253 registers are all taken,
+// and nothing derived from it can be hoisted out of the tile loop (and spilled)
+__device__ __forceinline__ int lane_now() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 // v * sigmoid(v), one value: v_mul, v_exp, v_add, v_rcp, v_mul as inline asm (left to hipcc, the SLP vectoriser pairs the
 // multiplies and adds into v_pk_* again).  hipcc's hazard recogniser does not look inside inline asm: a VALU instruction that
 // reads the result of a transcendental one needs a wait state, hence the s_nop in front of the add and the final multiply.
@@ -212,9 +220,7 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     constexpr int B_SLOT = S::SLOT;
     static_assert(!FUSE || NSEG == 3, "the gate weights need the LDS that three weight segments leave free");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int team = w >> 2, wq = w & 3;  // wq: SIMD = tile rows 2 wq, 2 wq + 1 (compute) = loader index
     const int nchunks = a.nchunks16;       // 32-channel chunks, >= 3 (the host guards)
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -270,8 +276,7 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         int b, y0, x0;
         tile_origin(mt, b, y0, x0);
         img_l = (const char*)a.in0 + (long long)b * a.p0 * plane_in;
-        int lane_ = lane;
-        asm volatile("" : "+v"(lane_));  // opaque: nothing below is hoisted across the K loop (whose registers are all taken)
+        const int lane_ = lane_now();
         // Tiles whose whole 10 x 50 halo (and the row of pad entries behind it) lies inside the image need no per-entry bounds
         // test: entry offset = ((plane H + py) W + px) 16 + delta(tile).  (Pad entries p >= 500 are never read by the compute
         // waves: whatever in-range bytes they fetch are harmless, and an out-of-range offset reads zeros.)
@@ -314,8 +319,7 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     auto wseg_piece = [&](auto i_tag, const char* s0, int pieces, char* dst) __attribute__((always_inline)) {
         constexpr int i = decltype(i_tag)::value;
         const int j = wq + 4 * i;
-        int lane_ = lane;
-        asm volatile("" : "+v"(lane_));  // opaque: the per-lane 64-bit offsets are not hoisted out of the tile loop (and spilled)
+        const int lane_ = lane_now();
         const uint32_t lo = (uint32_t)lane_ * 16u;  // scalar base + 32-bit lane offset
         if (j < pieces) glds16(s0 + (size_t)(lo + (uint32_t)j * 1024u), dst + j * 1024);
     };
@@ -328,11 +332,12 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     // per tile and lane: pix = byte offset of the lane's pixel of fragment 0 inside a plane (D2S: of its 2 x 2 target block),
     // eoff[n] = offset of the entry of pair n relative to pix, or 0xffffffff where the channel does not exist
     __amdgpu_buffer_rsrc_t orsrc;
+    __amdgpu_buffer_rsrc_t xrsrc;  // FUSE: the block input x (in1) of the finished tile's image
+    uint32_t x_lane = 0;           // FUSE: offset of the lane's 8 bytes of channel fragment 0 relative to e_pix
     uint32_t e_pix = 0, eoff[NT] = {0, 0, 0};
     int e_c = 0, e_y = 0;
     auto epi_setup = [&]() __attribute__((always_inline)) {
-        int lane_ = lane;
-        asm volatile("" : "+v"(lane_));
+        const int lane_ = lane_now();
         const int g = lane_ >> 4, c = lane_ & 15;
         const int lane_cu = 2 * (g & 1) + (g >> 1);  // 16-byte unit of the lane inside a channel-fragment pair's 4 planes (entry16())
         int d_b, d_y0, d_x0;
@@ -362,6 +367,11 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
             e_pix = ((uint32_t)e_y * (uint32_t)a.W + (uint32_t)e_c) * 16u;
 #pragma unroll
             for (int n = 0; n < NT; ++n) eoff[n] = (uint32_t)(4 * n + lane_cu) * (uint32_t)plane_o;  // planes that do not exist fall out of range
+            if constexpr (FUSE) {
+                // x in ACCUMULATOR layout: channels 16 nf + 4 g .. + 3 of the lane's pixel = 8 bytes (g & 1) of plane 2 nf + (g >> 1)
+                xrsrc = __builtin_amdgcn_make_buffer_rsrc((char*)a.in1 + (long long)d_b * a.p1 * plane_o, 0, (int)(uint32_t)(a.p1 * plane_o), 0x00020000);
+                x_lane = (uint32_t)(g >> 1) * (uint32_t)plane_o + (uint32_t)(g & 1) * 8u;
+            }
         }
     };
     // entry E = 3 pf + n, worked on in four QUARTERS (accumulator register j of the pair's two fragments): v_permlane16_swap pairs
@@ -397,6 +407,71 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         if (!inside || eoff[n] == 0xffffffffu) off = 0xffffffffu;
         __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, (int)off, 0, 0);
     };
+    // ---- FUSE (conv2 + AdaptiveResidualMix, model.py:826-839), one pixel fragment pf of the finished tile in three parts:
+    //   A: x (the block input, a.in1) arrives in ACCUMULATOR layout, 8 bytes per channel fragment and lane; z is rounded to the
+    //      storage type and packed into MFMA B operands (two 16-channel accumulator fragments = one 32-wide K step);
+    //   C: gate beta = Wx.x + Wz.z on the MFMA: both halves of the gate weights are packed in accumulator-row order
+    //      (PackArgs::frag16 = 2), so a pair of x fragments IS a B operand too -- x is fetched once; the 36 KB of gate weights
+    //      stay in LDS for the whole launch;
+    //   D: blend x + sigmoid(alpha) sigmoid(beta) (z - x) into the accumulator registers, then the three entries as usual.
+    // The arithmetic is conv3s_kernel<.., FUSE>'s, operation for operation (identical bits).
+    uint32_t f_xq[NF][2];  // x of the pixel fragment in work: accumulator layout, two packed pairs per channel fragment
+    u32x4 f_zb[NT];        // its z as B operands (live from part A to part D of a chunk)
+    auto fuse_a = [&](auto pf_tag) __attribute__((always_inline)) {
+        constexpr int pf = decltype(pf_tag)::value;
+        const bool inside = e_y + pf / 3 < a.H && e_c + 16 * (pf % 3) < a.W;
+        const long long plane_o = (long long)a.H * a.W * 16;
+        uint32_t off = e_pix + (uint32_t)(pf / 3) * (uint32_t)a.W * 16u + (uint32_t)(16 * (pf % 3)) * 16u + x_lane;
+        if (!inside) off = 0xffffffffu;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+            const uint32_t o = inside ? off + (uint32_t)(2 * nf) * (uint32_t)plane_o : 0xffffffffu;  // planes >= p1 fall out of range: zeros
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(xrsrc, (int)o, 0, 0);
+            f_xq[nf][0] = v[0];
+            f_xq[nf][1] = v[1];
+        }
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            const f32x4 za = acc[pf][2 * m], zc = acc[pf][2 * m + 1];
+            u32x4 q;
+            q[0] = pack2r<TT>(za[0], za[1]); q[1] = pack2r<TT>(za[2], za[3]);
+            q[2] = pack2r<TT>(zc[0], zc[1]); q[3] = pack2r<TT>(zc[2], zc[3]);
+            asm volatile("" : "+v"(q));  // opaque: no pack -> unpack forwarding that would keep the floats alive
+            f_zb[m] = q;
+        }
+    };
+    auto fuse_c = [&](auto pf_tag) __attribute__((always_inline)) {
+        constexpr int pf = decltype(pf_tag)::value;
+        const int lane_ = lane_now();
+        const uint32_t mix_lane = lds_base + S::MIX_BASE + lane_ * 16;
+        u32x4 xb[NT];
+#pragma unroll
+        for (int m = 0; m < NT; ++m) xb[m] = u32x4{f_xq[2 * m][0], f_xq[2 * m][1], f_xq[2 * m + 1][0], f_xq[2 * m + 1][1]};
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) acc[pf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 wa[NT], wb[NT];
+        gate_reads<0, 0>(wa, mix_lane);
+        gate_halves<TT, 0>(acc[pf], xb, f_zb, wa, wb, mix_lane);
+    };
+    auto fuse_d = [&](auto pf_tag) __attribute__((always_inline)) {
+        constexpr int pf = decltype(pf_tag)::value;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+            float zv[4], xv[4];
+            unpack2r<TT>(f_zb[nf >> 1][(nf & 1) * 2], zv[0], zv[1]);
+            unpack2r<TT>(f_zb[nf >> 1][(nf & 1) * 2 + 1], zv[2], zv[3]);
+            unpack2r<TT>(f_xq[nf][0], xv[0], xv[1]);
+            unpack2r<TT>(f_xq[nf][1], xv[2], xv[3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[pf][nf][j] = xv[j] + a.mix_scale * sigmoidf_(acc[pf][nf][j]) * (zv[j] - xv[j]);
+        }
+    };
+    auto entry_whole = [&](auto e_tag) __attribute__((always_inline)) {
+        u32x4 o;
+        epi_quarter(e_tag, ic<0>{}, o); epi_quarter(e_tag, ic<1>{}, o); epi_quarter(e_tag, ic<2>{}, o); epi_quarter(e_tag, ic<3>{}, o);
+        epi_store(e_tag, o);
+    };
+
     auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int pf = 0; pf < NPF; ++pf)
@@ -405,8 +480,7 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     };
     // fragment stream of a tile's first groups: tap 0 of chunk 0 and the weight pairs of groups 0 and 1
     auto prime = [&](int wslot, int aslot) __attribute__((always_inline)) {
-        int lane_ = lane;
-        asm volatile("" : "+v"(lane_));
+        const int lane_ = lane_now();
         const int g = lane_ >> 4, c = lane_ & 15;
         const uint32_t ab = lds_base + aslot * A_SLOT + g * A_PLANE + ((2 * wq) * ROWW + c) * 16;
         const uint32_t bb = lds_base + B_BASE + wslot * B_SLOT + lane_ * 16;
@@ -428,8 +502,7 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     //      before it requests that tile's first halo image, and leaves a copy for the other team, which becomes the loader of
     //      tB's later chunks one tile on (it is in the compute role, without a free register, until then) ----
     auto aoff_table = [&]() __attribute__((always_inline)) {
-        int lane_ = lane;
-        asm volatile("" : "+v"(lane_));
+        const int lane_ = lane_now();
         return (u32x4*)(smem + S::AOFF_BASE + wq * 2048 + lane_ * 16);
     };
     auto aoff_publish = [&]() __attribute__((always_inline)) {
@@ -454,11 +527,14 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     const char* wA = nullptr;
     const char* wB = nullptr;
     bool okB = false;
-    auto loader_step = [&](auto es_tag, auto en_tag, auto sg_tag, auto last_tag, int k) __attribute__((always_inline)) {
-        constexpr int ES = decltype(es_tag)::value, EN = decltype(en_tag)::value, sg = decltype(sg_tag)::value;
+    auto loader_step = [&](auto wk_tag, auto es_tag, auto en_tag, auto sg_tag, auto last_tag, int k) __attribute__((always_inline)) {
+        constexpr int WK = decltype(wk_tag)::value;  // 1: entries [ES, ES + EN); 2 / 3 / 4: FUSE part A / C / D of EN pixel fragments from ES
+        constexpr int ES = decltype(es_tag)::value, EN = WK == 0 ? 0 : decltype(en_tag)::value, sg = decltype(sg_tag)::value;
         constexpr bool last = decltype(last_tag)::value != 0;
         constexpr int rs_c = 1 + (EN > 0 ? 2 : 0) + (sg == 0 ? 0 : 1);
         static_assert(EN <= 3, "three output registers");
+        // VMEM instructions this step issues BEHIND its DMA: stores of the entries, or FUSE's x loads
+        constexpr int VM_AFTER = WK == 1 ? EN : (WK == 2 ? EN * NF : (WK == 4 ? EN * NT : 0));
         RS_BEGIN();
         // ---- this step's DMA: in a chunk's first step the next chunk's halo image (first: its data comes from HBM and takes
         //      longest), then weight segment (k, sg) + 2 steps ----
@@ -493,13 +569,24 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         RS_LAP(4 * rs_c);
         // ---- this step's share of the finished tile's epilogue, behind the DMA issue: the arithmetic runs while the loads are in
         //      flight, the stores go out behind the step's last DMA piece (vmcnt: see the head of this file) ----
-        u32x4 o0, o1, o2;
-        if constexpr (EN > 0) { epi_quarter(ic<ES>{}, ic<0>{}, o0); epi_quarter(ic<ES>{}, ic<1>{}, o0); epi_quarter(ic<ES>{}, ic<2>{}, o0); epi_quarter(ic<ES>{}, ic<3>{}, o0); }
-        if constexpr (EN > 1) { epi_quarter(ic<ES + 1>{}, ic<0>{}, o1); epi_quarter(ic<ES + 1>{}, ic<1>{}, o1); epi_quarter(ic<ES + 1>{}, ic<2>{}, o1); epi_quarter(ic<ES + 1>{}, ic<3>{}, o1); }
-        if constexpr (EN > 2) { epi_quarter(ic<ES + 2>{}, ic<0>{}, o2); epi_quarter(ic<ES + 2>{}, ic<1>{}, o2); epi_quarter(ic<ES + 2>{}, ic<2>{}, o2); epi_quarter(ic<ES + 2>{}, ic<3>{}, o2); }
-        if constexpr (EN > 0) epi_store(ic<ES>{}, o0);
-        if constexpr (EN > 1) epi_store(ic<ES + 1>{}, o1);
-        if constexpr (EN > 2) epi_store(ic<ES + 2>{}, o2);
+        if constexpr (WK == 1) {
+            u32x4 o0, o1, o2;
+            if constexpr (EN > 0) { epi_quarter(ic<ES>{}, ic<0>{}, o0); epi_quarter(ic<ES>{}, ic<1>{}, o0); epi_quarter(ic<ES>{}, ic<2>{}, o0); epi_quarter(ic<ES>{}, ic<3>{}, o0); }
+            if constexpr (EN > 1) { epi_quarter(ic<ES + 1>{}, ic<0>{}, o1); epi_quarter(ic<ES + 1>{}, ic<1>{}, o1); epi_quarter(ic<ES + 1>{}, ic<2>{}, o1); epi_quarter(ic<ES + 1>{}, ic<3>{}, o1); }
+            if constexpr (EN > 2) { epi_quarter(ic<ES + 2>{}, ic<0>{}, o2); epi_quarter(ic<ES + 2>{}, ic<1>{}, o2); epi_quarter(ic<ES + 2>{}, ic<2>{}, o2); epi_quarter(ic<ES + 2>{}, ic<3>{}, o2); }
+            if constexpr (EN > 0) epi_store(ic<ES>{}, o0);
+            if constexpr (EN > 1) epi_store(ic<ES + 1>{}, o1);
+            if constexpr (EN > 2) epi_store(ic<ES + 2>{}, o2);
+        } else if constexpr (WK == 2) {
+            static_assert(WK != 2 || EN == 1, "one pixel fragment per chunk");
+            fuse_a(ic<ES>{});
+        } else if constexpr (WK == 3) {
+            fuse_c(ic<ES>{});
+        } else if constexpr (WK == 4) {
+            // the entries' stores must be this step's ONLY vector-memory instructions behind its DMA: all blends first
+            fuse_d(ic<ES>{});
+            entry_whole(ic<3 * ES>{}); entry_whole(ic<3 * ES + 1>{}); entry_whole(ic<3 * ES + 2>{});
+        }
         if constexpr (sg == NSEG - 1) {
             if constexpr (last) {
                 // the epilogue is complete: clear the accumulators and prime the fragment stream for the next tile.  Unconditional
@@ -509,27 +596,40 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
             } else {
                 if (k + 2 == nchunks && okB) {  // the next step requests tB's first halo image
                     set_load_tile(b_mt);
-                    aoff_publish();
+                    if constexpr (!FUSE) aoff_publish();
                 }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         RS_LAP(4 * rs_c + 1);
         // the DMA has landed once at most this step's stores (issued behind it) are outstanding
-        wait_vmcnt<EN>();
+        wait_vmcnt<VM_AFTER>();
         RS_LAP(4 * rs_c + 2);
         __builtin_amdgcn_s_barrier();
         RS_LAP(4 * rs_c + 3);
         RS_COUNT(20 + rs_c);
         hs = next3(hs);
+        if constexpr (sg == NSEG - 1) us ^= 1;  // the chunk is complete
     };
-    // chunk iteration k; E0 = its first entry, N0 / N1 = entries of its first / second step
+    // chunk iteration k of the plain variants; E0 = its first entry, N0 / N1 = entries of its first / second step
     auto loader_chunk = [&](auto e0_tag, auto n0_tag, auto n1_tag, auto last_tag, int k) __attribute__((always_inline)) {
         constexpr int E0 = decltype(e0_tag)::value, N0 = decltype(n0_tag)::value, N1 = decltype(n1_tag)::value;
-        static_assert(NSEG == 2, "schedule of the plain variants");
-        loader_step(ic<E0>{}, ic<N0>{}, ic<0>{}, last_tag, k);
-        loader_step(ic<E0 + N0>{}, ic<N1>{}, ic<1>{}, last_tag, k);
-        us ^= 1;
+        if constexpr (NSEG == 2) {
+            loader_step(ic<(N0 > 0)>{}, ic<E0>{}, ic<N0>{}, ic<0>{}, last_tag, k);
+            loader_step(ic<(N1 > 0)>{}, ic<E0 + N0>{}, ic<N1>{}, ic<1>{}, last_tag, k);
+        } else {  // three steps: the first (halo image) takes N0, the other two share N1
+            constexpr int N1a = N1 / 2, N1b = N1 - N1a;
+            loader_step(ic<(N0 > 0)>{}, ic<E0>{}, ic<N0>{}, ic<0>{}, last_tag, k);
+            loader_step(ic<(N1a > 0)>{}, ic<E0 + N0>{}, ic<N1a>{}, ic<1>{}, last_tag, k);
+            loader_step(ic<(N1b > 0)>{}, ic<E0 + N0 + N1a>{}, ic<N1b>{}, ic<2>{}, last_tag, k);
+        }
+    };
+    // chunk iteration k of the fused variant: parts A, C, D of G pixel fragments from P0 in its three steps
+    auto fuse_chunk = [&](auto p0_tag, auto g_tag, auto last_tag, int k) __attribute__((always_inline)) {
+        static_assert(!FUSE || NSEG == 3, "the fused variant runs three steps per chunk");
+        loader_step(ic<2>{}, p0_tag, g_tag, ic<0>{}, last_tag, k);
+        loader_step(ic<3>{}, p0_tag, g_tag, ic<1>{}, last_tag, k);
+        loader_step(ic<4>{}, p0_tag, g_tag, ic<NSEG - 1>{}, last_tag, k);
     };
     auto plain_chunks = [&](int k0) __attribute__((always_inline)) {  // chunks k0 .. nchunks - 1 without epilogue work
         for (int k = k0; k + 1 < nchunks; ++k) loader_chunk(ic<0>{}, ic<0>{}, ic<0>{}, ic<0>{}, k);
@@ -541,11 +641,25 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         okB = b_pos < cnt;
         wB = wsrc_of(okB ? b_nt : a_nt);
         if constexpr (DO_EPI) {
-            aoff_fetch(a_mt);
+            if constexpr (FUSE) set_load_tile(a_mt);  // (no room in LDS for the offset hand-off next to the gate weights)
+            else aoff_fetch(a_mt);
             epi_setup();
-            // The 18 entries are spread over the tile's first six chunks where it has six (1 + 2 per chunk: the first step also
-            // carries the halo image), else over its first three (3 + 3).
-            if (nchunks >= 6) {
+            if constexpr (FUSE) {
+                // one pixel fragment per chunk: the tile has at least six chunks (C = 96: Cin = 192; the host guards)
+                fuse_chunk(ic<0>{}, ic<1>{}, ic<0>{}, 0);
+                fuse_chunk(ic<1>{}, ic<1>{}, ic<0>{}, 1);
+                fuse_chunk(ic<2>{}, ic<1>{}, ic<0>{}, 2);
+                fuse_chunk(ic<3>{}, ic<1>{}, ic<0>{}, 3);
+                fuse_chunk(ic<4>{}, ic<1>{}, ic<0>{}, 4);
+                if (nchunks == 6) {
+                    fuse_chunk(ic<5>{}, ic<1>{}, ic<1>{}, 5);
+                } else {
+                    fuse_chunk(ic<5>{}, ic<1>{}, ic<0>{}, 5);
+                    plain_chunks(6);
+                }
+            } else if (nchunks >= 6) {
+                // The 18 entries are spread over the tile's first six chunks where it has six (1 + 2 per chunk: the first step also
+                // carries the halo image), else over its first three (3 + 3).
                 loader_chunk(ic<0>{}, ic<1>{}, ic<2>{}, ic<0>{}, 0);
                 loader_chunk(ic<3>{}, ic<1>{}, ic<2>{}, ic<0>{}, 1);
                 loader_chunk(ic<6>{}, ic<1>{}, ic<2>{}, ic<0>{}, 2);
@@ -576,8 +690,7 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     // compute role: the K loop of tile tA (conv3q_kernel's compute wave)
     // ------------------------------------------------------------------------------------------------
     auto compute_phase = [&]() __attribute__((always_inline)) {
-        int lane_ = lane;
-        asm volatile("" : "+v"(lane_));
+        const int lane_ = lane_now();
         const int g = lane_ >> 4, c = lane_ & 15;
         const uint32_t a_lane = lds_base + g * A_PLANE + ((2 * wq) * ROWW + c) * 16;
         Bases bs;
@@ -636,11 +749,22 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         epi_quarter(e_tag, ic<0>{}, o); epi_quarter(e_tag, ic<1>{}, o); epi_quarter(e_tag, ic<2>{}, o); epi_quarter(e_tag, ic<3>{}, o);
         epi_store(e_tag, o);
     };
+    auto final_fuse_pf = [&](auto pf_tag) __attribute__((always_inline)) {
+        constexpr int pf = decltype(pf_tag)::value;
+        fuse_a(pf_tag);
+        fuse_c(pf_tag);
+        fuse_d(pf_tag);
+        entry_whole(ic<3 * pf>{}); entry_whole(ic<3 * pf + 1>{}); entry_whole(ic<3 * pf + 2>{});
+    };
     auto final_epilogue = [&]() __attribute__((always_inline)) {
         epi_setup();
-        final_entry(ic<0>{}); final_entry(ic<1>{}); final_entry(ic<2>{}); final_entry(ic<3>{}); final_entry(ic<4>{}); final_entry(ic<5>{});
-        final_entry(ic<6>{}); final_entry(ic<7>{}); final_entry(ic<8>{}); final_entry(ic<9>{}); final_entry(ic<10>{}); final_entry(ic<11>{});
-        final_entry(ic<12>{}); final_entry(ic<13>{}); final_entry(ic<14>{}); final_entry(ic<15>{}); final_entry(ic<16>{}); final_entry(ic<17>{});
+        if constexpr (FUSE) {
+            final_fuse_pf(ic<0>{}); final_fuse_pf(ic<1>{}); final_fuse_pf(ic<2>{}); final_fuse_pf(ic<3>{}); final_fuse_pf(ic<4>{}); final_fuse_pf(ic<5>{});
+        } else {
+            final_entry(ic<0>{}); final_entry(ic<1>{}); final_entry(ic<2>{}); final_entry(ic<3>{}); final_entry(ic<4>{}); final_entry(ic<5>{});
+            final_entry(ic<6>{}); final_entry(ic<7>{}); final_entry(ic<8>{}); final_entry(ic<9>{}); final_entry(ic<10>{}); final_entry(ic<11>{});
+            final_entry(ic<12>{}); final_entry(ic<13>{}); final_entry(ic<14>{}); final_entry(ic<15>{}); final_entry(ic<16>{}); final_entry(ic<17>{});
+        }
     };
 
     // ------------------------------------------------------------------------------------------------
@@ -661,6 +785,12 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
             wseg_piece(ic<0>{}, s1, S::pieces(1), d1); wseg_piece(ic<1>{}, s1, S::pieces(1), d1); wseg_piece(ic<2>{}, s1, S::pieces(1), d1);
             wseg_piece(ic<3>{}, s1, S::pieces(1), d1); wseg_piece(ic<4>{}, s1, S::pieces(1), d1); wseg_piece(ic<5>{}, s1, S::pieces(1), d1);
             wseg_piece(ic<6>{}, s1, S::pieces(1), d1);
+        }
+        if constexpr (FUSE) {  // the gate weights, resident for the whole launch: 36 pieces, 9 per wave
+            const int lane_ = lane_now();
+            const char* msrc = (const char*)a.wmix16 + (uint32_t)lane_ * 16u;
+#pragma unroll
+            for (int i = 0; i < MIX_PIECES / 4; ++i) glds16(msrc + (size_t)(wq + 4 * i) * 1024, smem + S::MIX_BASE + (wq + 4 * i) * 1024);
         }
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();  // B_0

@@ -24,6 +24,7 @@ template <class TT> static hipError_t r_epi(const ConvArgs& a, hipStream_t s) {
     switch (a.epi) {
         case EPI_STORE: return r_launch<TT, MZ_R_NSEG, EPI_STORE>(a, s);
         case EPI_D2S: return r_launch<TT, MZ_R_NSEG, EPI_D2S>(a, s);
+        case EPI_FUSEDMIX: return a.wmix16 ? r_launch<TT, 3, EPI_FUSEDMIX>(a, s) : hipErrorInvalidValue;  // wmix16: PackArgs::frag16 = 2
         default: return hipErrorInvalidValue;
     }
 }

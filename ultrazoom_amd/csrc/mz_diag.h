@@ -21,7 +21,7 @@
 #define RS_COUNT(i) do { rs_[i] += 1; } while (0)
 #define RS_DUMP()                                                                                              \
     do {                                                                                                       \
-        if (a.dbg && blockIdx.x == gridDim.x / 2 && lane == 0) {                                               \
+        if (a.dbg && blockIdx.x == gridDim.x / 2 && (threadIdx.x & 63) == 0) {                                               \
             _Pragma("unroll") for (int i__ = 0; i__ < 32; ++i__) a.dbg[w * 32 + i__] = rs_[i__];              \
         }                                                                                                      \
     } while (0)

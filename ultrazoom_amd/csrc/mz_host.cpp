@@ -105,6 +105,7 @@ struct ConvW {
     void* packed16 = nullptr;
     size_t packed16_sz = 0;
     int nchunks16 = 0;
+    void* packed16r = nullptr;  // fused gate weights once more, both halves in accumulator-row order (conv3r_kernel; PackArgs::frag16 = 2)
     bool set = false;
 };
 
@@ -350,6 +351,8 @@ static void free_conv(ConvW& c) {
     c.packed = nullptr;
     if (c.packed16) (void)hipFree(c.packed16);
     c.packed16 = nullptr;
+    if (c.packed16r) (void)hipFree(c.packed16r);
+    c.packed16r = nullptr;
 }
 
 extern "C" int mz_destroy(mz_handle* h) {
@@ -411,6 +414,11 @@ static int pack_conv(ConvW& c, int dtype, const float* w_dev, hipStream_t s) {
         p.dst = c.packed16; p.frag16 = 1; p.nchunks = c.nchunks16;
         if (c.in_map == SRC_CONCAT) { p.nt = 6; p.ntiles = c.cout / 192; }  // mix16_kernel: 12 fragments per K step
         HIPCHK(launch_pack(p, s));
+        if (c.in_map == SRC_MIXF && c.nt == 3) {
+            if (!c.packed16r) HIPCHK(hipMalloc(&c.packed16r, c.packed16_sz));
+            p.dst = c.packed16r; p.frag16 = 2;
+            HIPCHK(launch_pack(p, s));
+        }
     }
     c.set = true;
     return MZ_OK;
@@ -716,6 +724,32 @@ struct Runner {
                            (epi == EPI_D2S ? (double)(c.cq_p * dtype_size(dtype) / 16) * Hout * Wout * 16.0 < 4294967296.0
                                            : 12.0 * H * W * 16.0 < 4294967296.0);
         const bool use_q = use_r || (knobs.q && q_common && c.nchunks16 % 2 == 0);
+        // ... and its fused variant (conv2 + AdaptiveResidualMix, C = 96): six or more chunks (one pixel fragment's gate GEMM and
+        // blend per chunk), the gate weights packed in accumulator-row order, x and out within 32-bit offsets
+        bool use_rf = knobs.r && knobs.fuse16 && epi == EPI_FUSEDMIX && use_s16 && dtype != DT_F32 && c.nt == 3 && c.ntiles == 1 && c.packed16 &&
+                      mixf && mixf->packed16r && (mixf->cp0 + 31) / 32 == c.nt && persist_wgs > 0 && c.nchunks16 >= 6 &&
+                      c.nchunks16 * 32 * 100 <= c.cp0 * (100 + knobs.kpad_pct) && (double)H * W * 64.0 < 4294967296.0 &&
+                      12.0 * H * W * 16.0 < 4294967296.0;
+        if (use_rf) {
+            const long long padq = (long long)((H + 7) / 8 * 8) * ((W + 47) / 48 * 48);
+            const long long pads = (long long)a.tiles_y * th * a.tiles_x * tw;
+            use_rf = padq <= pads;
+        }
+        if (use_rf) {
+            a.tiles_x = (W + 47) / 48; a.tiles_y = (H + 7) / 8;
+            a.mtiles = B * a.tiles_x * a.tiles_y;
+            pick_order(a, c, px * c.cp0 * sz);
+            a.s16 = 1; a.wpk16 = c.packed16; a.nchunks16 = c.nchunks16;
+            a.wmix16 = mixf->packed16r;
+            const int need = (a.grid + 7) / 8 * 8;
+            a.persist = need < persist_wgs ? need : persist_wgs;
+            ProfRec* r;
+            prof_begin(r, 2.0 * px * 9.0 * c.cin * c.cout + extra_flops, px * (c.cin + c.cout) * sz + 9.0 * c.cin * c.cout * sz + px * c.cout * sz, 1);
+            if (r) { r->kind = 0; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.gm * 1000 + a.gn; }
+            check(launch_conv3r(dtype, a, s), "conv3r fused launch");
+            prof_end(r);
+            return;
+        }
         if (use_q) {
             a.tiles_x = (W + 47) / 48; a.tiles_y = (H + 7) / 8;
             a.mtiles = B * a.tiles_x * a.tiles_y;
@@ -1023,6 +1057,50 @@ extern "C" int mz_op_conv(int dtype, int kind, const void* in0, const void* in1,
         case 2: run.crush(c, in0, out, B, H, W); break;
         case 3: run.mix(c, alpha, in0, in1, out, B, H, W); break;
     }
+    fake.zero_page = nullptr;
+    HIPCHK(hipStreamSynchronize(s));
+    return run.rc;
+}
+
+// conv2 of a block + AdaptiveResidualMix with the block input in ONE launch (model.py:773-778 second half, 826-839): the fused
+// kernels of the 16-bit modes (conv3r_kernel / conv3s_kernel / conv3w_kernel with FUSE), for C <= 96.
+//   hid [B, cin, H, W] (conv1's activated output), x [B, cout, H, W] (the block input), w2 [cout, cin, 3, 3], wmix [cout, 2 cout, 1, 1]
+extern "C" int mz_op_conv_mix(int dtype, const void* hid, const void* x, const float* w2_dev_f32, const float* wmix_dev_f32, float alpha,
+                              void* out, int B, int H, int W, int cin, int cout, void* hip_stream) {
+    int rc = ensure_device_ready();
+    if (rc) return rc;
+    if (!hid || !x || !w2_dev_f32 || !wmix_dev_f32 || !out) return fail(MZ_ERR_INVALID_ARGUMENT, "null argument");
+    hipStream_t s = (hipStream_t)hip_stream;
+    ConvW c2;
+    plan_conv(c2, dtype, MODE_CONV3, cout, cin, 3, 3, OUT_PLAIN, SRC_PLAIN, 0, 0);
+    if (!(c2.ntiles == 1 && c2.nt <= 3)) return fail(MZ_ERR_INVALID_ARGUMENT, "the fused conv2 + mix needs all output channels in one N tile (cout <= 96)");
+    ConvW f;  // as plan_model()'s BlockW::mixf
+    f.cout = cout; f.cin = 2 * cout; f.kh = f.kw = 1;
+    f.mode = MODE_GEMM1; f.taps = 1;
+    f.nt = c2.nt; f.ntiles = 1;
+    f.out_map = OUT_PLAIN; f.in_map = SRC_MIXF;
+    f.c0 = cout; f.cp0 = pad16(cout); f.c1 = cout;
+    const int zg = dtype == DT_F32 ? 4 : 2;
+    f.nchunks = f.nchunks_real = f.cp0 / chunk_channels(dtype) + f.nt * zg;
+    f.packed_sz = packed_bytes(1, f.nt, 1, f.nchunks);
+    if (dtype != DT_F32) {
+        f.nchunks16 = (f.cp0 + 31) / 32 + f.nt;
+        f.packed16_sz = packed_bytes(1, 2 * f.nt, 1, f.nchunks16);
+    }
+    TempBuf zero, p0, p1, p2, p3, p4;
+    HIPCHK(hipMalloc(&zero.p, 4096));
+    HIPCHK(hipMemsetAsync(zero.p, 0, 4096, s));
+    rc = pack_conv(c2, dtype, w2_dev_f32, s);
+    p0.p = c2.packed; p1.p = c2.packed16;
+    if (rc) return rc;
+    rc = pack_conv(f, dtype, wmix_dev_f32, s);
+    p2.p = f.packed; p3.p = f.packed16; p4.p = f.packed16r;
+    if (rc) return rc;
+    mz_handle fake;
+    fake.zero_page = zero.p;
+    fake.knobs = read_knobs();
+    Runner run{&fake, s, dtype};
+    run.conv3(c2, hid, out, B, H, W, EPI_FUSEDMIX, 0, 0, 0, nullptr, 0, 0, nullptr, &f, x, alpha);
     fake.zero_page = nullptr;
     HIPCHK(hipStreamSynchronize(s));
     return run.rc;

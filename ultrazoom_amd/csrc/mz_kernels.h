@@ -93,7 +93,8 @@ hipError_t launch_conv3q(int dtype, const ConvArgs& a, hipStream_t s);
 hipError_t init_conv3q();
 // conv3r_kernel (mz_conv3r.h): the same tile shape and K loop, but the two waves of every SIMD alternate between the compute
 // and the loader + epilogue role from tile to tile.  >= 3 chunks of 32 channels (odd counts included); EPI_STORE / EPI_D2S
-// (32-bit store offsets: 12 planes of the output, resp. one whole D2S target image, must stay below 4 GiB).
+// (32-bit store offsets: 12 planes of the output, resp. one whole D2S target image, must stay below 4 GiB); EPI_FUSEDMIX: >= 6
+// chunks, a.wmix16 = gate weights packed with PackArgs::frag16 = 2, a.in1 / a.p1 = the block input.
 hipError_t launch_conv3r(int dtype, const ConvArgs& a, hipStream_t s);
 
 // ---- weight packing ---------------------------------------------------------------------------
@@ -108,7 +109,8 @@ struct PackArgs {
     int out_map;       // OutMap
     int cq, cq_p;      // D2S: real / padded channels per output pixel
     int in_map;        // SrcKind
-    int frag16;        // 1: fragments of the 16x16x32 MFMA (16 channels x 32 K; 16-bit types, SRC_PLAIN only); nchunks counts 32-channel chunks
+    int frag16;        // 1: fragments of the 16x16x32 MFMA (16 channels x 32 K; 16-bit types); nchunks counts 32-channel chunks.  2 (SRC_MIXF): ... with
+                       // the x half of the gate weights in accumulator-row order as well (conv3r_kernel's fused variant)
     int c0, cp0, c1;   // CONCAT: real/padded channels of in0, real channels of in1;  PLAIN/CRUSH: c0 = cin, cp0 = padded cin
 };
 size_t packed_bytes(int taps, int nt, int ntiles, int nchunks);

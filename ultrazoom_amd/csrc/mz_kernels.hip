@@ -2050,7 +2050,13 @@ template <class TT> __global__ void pack_kernel(const PackArgs a, long long tota
         // K-step per PAIR of 16-channel accumulator fragments of z, K elements in the order the accumulator quads of
         // lane group g = lane >> 4 supply them: e < 4 -> fragment 2m, channel 4g + e; e >= 4 -> fragment 2m + 1
         const int ncx = (a.cp0 + 31) / 32;
-        if (kc < ncx) {
+        if (kc < ncx && a.frag16 == 2) {
+            // conv3r_kernel's fused variant: the x half in accumulator-row order too (x is fetched in accumulator layout, so
+            // that a pair of its channel fragments is a B operand as it stands)
+            const int g = lane >> 4;
+            const int xch = 32 * kc + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4));
+            ci = xch < a.c0 ? xch : -1;
+        } else if (kc < ncx) {
             const int k = kc * 32 + kin;
             ci = k < a.c0 ? k : -1;
         } else {
