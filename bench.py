@@ -57,10 +57,10 @@ MODELS = {
                  hidden_ratio=2, num_deg_features=3),
 }
 WORKLOADS = {
-    # name: (model, images per GPU, H, W, description)
-    "cfg3_1080p": ("4x96", 16, 1080, 1920, "MewZoom-4X 96ch/40L bf16, 16 x 1080x1920 -> 4320x7680 per GPU"),
-    "cfg3_540p": ("4x96", 16, 540, 960, "MewZoom-4X 96ch/40L bf16, 16 x 540x960 -> 2160x3840 (4K) per GPU"),
-    "cfg2": ("2x48", 32, 540, 960, "MewZoom-2X 48ch/20L bf16, 32 x 540x960 -> 1080x1920 per GPU"),
+    # name: (model, images per GPU, H, W, description; {dtype} = the --dtype of the run)
+    "cfg3_1080p": ("4x96", 16, 1080, 1920, "MewZoom-4X 96ch/40L {dtype}, 16 x 1080x1920 -> 4320x7680 per GPU"),
+    "cfg3_540p": ("4x96", 16, 540, 960, "MewZoom-4X 96ch/40L {dtype}, 16 x 540x960 -> 2160x3840 (4K) per GPU"),
+    "cfg2": ("2x48", 32, 540, 960, "MewZoom-2X 48ch/20L {dtype}, 32 x 540x960 -> 1080x1920 per GPU"),
 }
 DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}  # dense MFMA, MI355X_MICROARCH.md
@@ -169,7 +169,7 @@ def cpu_baseline(cfg, sd, model, dtype, sample_hw):
         "gpu_vs_oracle_psnr_db": 10.0 * math.log10(1.0 / mse) if mse > 0 else float("inf"),
         "gpu_vs_oracle_max_abs": (got - want).abs().max().item(),
         "cfg1": cpu_baseline_cfg1(cores),
-    }
+    }, want
 
 
 def cpu_baseline_cfg1(cores):
@@ -199,6 +199,89 @@ def cpu_baseline_cfg1(cores):
     }
 
 
+def free_port() -> int:
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a CHILD process (one rank per GPU, rendezvous
+    on 127.0.0.1), relay what they print -- rank 0's JSON line -- and return their exit code.  The parent never touches the
+    GPU (a process that has initialised HIP must not exec, and need not: it only waits)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def timed_steps(step, sync, steps, warmup):
+    for _ in range(warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    return time.perf_counter() - t0
+
+
+def secondary_readings(device, want_sample, sample_hw):
+    """Short same-process runs of the other BASELINE readings, so that they are driver-timed too (rank 0, N = 1):
+    cfg2 (BASELINE configs[1]) in bf16, the headline workload in fp16 (north_star's Target sentence), and the fp32
+    verification mode against the CPU oracle on the cpu_baseline sample (north_star: <= 1e-3 max-abs)."""
+    out = {}
+
+    def run(workload, dtype_name, steps, warmup):
+        model_name, per_gpu, H, W, desc = WORKLOADS[workload]
+        cfg = MODELS[model_name]
+        dtype = DTYPES[dtype_name]
+        sd = synth_state_dict(parameter_shapes(cfg), seed=1234)
+        m = MewZoom(**cfg)
+        m.load_state_dict(sd)
+        m = m.to(device, dtype).eval()
+        x = synth_image(per_gpu, H, W, seed=1000).to(device, dtype)
+        el = timed_steps(lambda: m.upscale(x), lambda: torch.cuda.synchronize(device), steps, warmup)
+        r = cfg["upscale_ratio"]
+        h = m._engine.handle
+        h.profile_enable(True)
+        m.upscale(x)
+        torch.cuda.synchronize(device)
+        prof = h.profile_read()
+        h.profile_enable(False)
+        conv_tflops = prof["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12 if prof["conv_ms"] > 0 else 0.0
+        res = {"workload": desc.format(dtype=dtype_name), "value": per_gpu * H * r * W * r / 1e6 * steps / el, "unit": "MPix/s",
+               "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3, "conv3x3_tflops": conv_tflops,
+               "conv3x3_frac_of_peak": conv_tflops / PEAK_TFLOPS[dtype_name]}
+        del m, x
+        torch.cuda.empty_cache()
+        return res
+
+    out["cfg2"] = run("cfg2", "bf16", 5, 2)
+    out["f16"] = run("cfg3_1080p", "f16", 2, 1)
+    if want_sample is not None:
+        cfg = MODELS["4x96"]
+        sd = synth_state_dict(parameter_shapes(cfg), seed=1234)
+        m = MewZoom(**cfg)
+        m.load_state_dict(sd)
+        m = m.to(device, torch.float32).eval()
+        h, w = sample_hw
+        got = m.upscale(synth_image(1, h, w, seed=99).to(device, torch.float32)).float().cpu()
+        out["f32_max_abs"] = (got - want_sample).abs().max().item()
+        out["f32_sample"] = f"fp32 mode of the headline model vs the CPU oracle on 1x3x{h}x{w} (north_star tolerance: 1e-3 max-abs)"
+        del m
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,7 +295,12 @@ def main():
     ap.add_argument("--dump-launches", default="", help="write a per-launch CSV (shape, ms, TFLOP/s) of the profiled step")
     ap.add_argument("--no-gather", action="store_true", help="skip the output gather in the timed step (N > 1)")
     ap.add_argument("--images-per-gpu", type=int, default=0, help="override the workload's batch (profiling runs only)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short cfg2 / fp16 / fp32 side readings (N = 1)")
+    ap.add_argument("--dry-run", action="store_true", help="rendezvous, barrier and JSON line only: no GPU work (launcher tests)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -225,6 +313,19 @@ def main():
     mfma_peak = measured_mfma_peak() if (rank == 0 and world == 1 and not args.no_microbench) else None
     # one rank per GPU; MZ_BENCH_BACKEND=gloo lets several ranks share one GPU for plumbing rehearsals on a 1-GPU box
     backend = os.environ.get("MZ_BENCH_BACKEND", "nccl")
+    if args.dry_run:  # the launcher's plumbing without a GPU: rendezvous over gloo, one all-reduce, rank 0's line
+        if world > 1:
+            dist.init_process_group("gloo")
+            t = torch.tensor([float(rank)], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            assert int(t.item()) == world - 1
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"metric": "dry run", "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "dry_run": True}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     ndev = torch.cuda.device_count()
     dev_index = local_rank if backend == "nccl" else local_rank % max(1, ndev)
     torch.cuda.set_device(dev_index)
@@ -239,6 +340,7 @@ def main():
     if args.images_per_gpu > 0:
         per_gpu = args.images_per_gpu
         desc += f" [batch overridden to {per_gpu}: profiling run, not a benchmark result]"
+    desc = desc.format(dtype=args.dtype)
     cfg = MODELS[model_name]
     dtype = DTYPES[args.dtype]
     r = cfg["upscale_ratio"]
@@ -269,18 +371,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    def max_over_ranks(sec):
+        if world > 1:
+            t = torch.tensor([sec], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return t.item()
+        return sec
+
+    elapsed = max_over_ranks(timed_steps(step, sync, args.steps, args.warmup))
+    # N > 1: the compute-only rate as well (the same steps without the gather), reported next to the headline value
+    elapsed_no_gather = None
+    if do_gather:
+        elapsed_no_gather = max_over_ranks(timed_steps(lambda: model.upscale(x), sync, args.steps, 1))
 
     out_mpix_per_step = global_batch * (H * r) * (W * r) / 1e6
     value = out_mpix_per_step * args.steps / elapsed
@@ -325,6 +427,7 @@ def main():
                 "images_in_flight": args.images_in_flight,
             },
             "whole_path_tflops_per_gpu": flops_step * args.steps / elapsed / 1e12,
+            "value_without_gather": out_mpix_per_step * args.steps / elapsed_no_gather if elapsed_no_gather else None,
             "roofline": {
                 "bound": "mfma",
                 "kernel": "3x3 implicit-GEMM convolution kernels (all 3x3 launches of one step, rank 0)",
@@ -351,9 +454,14 @@ def main():
                 "algorithmic_GBps": prof["conv_bytes"] / (prof["conv_ms"] * 1e-3) / 1e9 if prof["conv_ms"] > 0 else 0.0,
             },
         }
+        want_sample = None
+        sample = (384, 640) if model_name == "4x96" else (540, 960)  # ~10-20 s of CPU work in total
         if not args.no_cpu_baseline and world == 1:
-            sample = (384, 640) if model_name == "4x96" else (540, 960)  # ~10-20 s of CPU work in total
-            result["cpu_baseline"] = cpu_baseline(cfg, sd, model, dtype, sample)
+            result["cpu_baseline"], want_sample = cpu_baseline(cfg, sd, model, dtype, sample)
+        if world == 1 and not args.no_secondary and args.workload == "cfg3_1080p" and args.dtype == "bf16" and args.images_per_gpu == 0:
+            del x
+            torch.cuda.empty_cache()
+            result["secondary"] = secondary_readings(device, want_sample, sample)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -1,0 +1,59 @@
+"""Build-time guard on the properties the hot kernels depend on: no scratch memory and no spilled vector registers.
+
+Several 2x regressions of earlier rounds came from hipcc spilling a handful of VGPRs of a kernel that lives at its register
+cap; nothing failed when that happened.  This test compiles the kernel translation units for gfx950
+(device code only, no GPU needed) with -Rpass-analysis=kernel-resource-usage and fails if a persistent 3x3 kernel, the mix
+kernel or the image head reports ScratchSize != 0 or VGPR spills."""
+
+import re
+import shutil
+import subprocess
+from pathlib import Path
+
+import pytest
+
+CSRC = Path(__file__).resolve().parent.parent / "ultrazoom_amd" / "csrc"
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+# kernels the execution plans of the 16-bit modes use (name prefix of the demangled-ish symbol)
+HOT = ("conv3r_kernel", "conv3q_kernel", "conv3s_kernel", "mix16_kernel", "conv3w_kernel")
+# Instantiations that are NOT on the default plans of the 16-bit modes and are known to spill (fallbacks / A-B knobs):
+#   conv3s_kernel<T, NT = 3, *, FUSE>: the C = 65..96 fused conv2 + mix; conv3r_kernel's fused variant takes it wherever the tile has six
+#                                      or more chunks (hidden_ratio >= 2), so this one only runs for hidden_ratio 1 or MZ_NO_R=1
+#   conv3w_kernel<T16, NT = 3, ..>:    per-tile wide kernels of the 16-bit types, reachable with MZ_NO_PERSIST=1 / MZ_NO_FUSE16=1 only
+EXEMPT = (re.compile(r"conv3s_kernelINS_\w+ELi3ELi\dELb1E"), re.compile(r"conv3w_kernelINS_\w+ELi3ELi\dELb[01]E"))
+
+
+def resource_usage(src: str):
+    p = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-c", "-Rpass-analysis=kernel-resource-usage",
+                        str(CSRC / src), "-o", "/dev/null"], capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = {}
+    name = None
+    for line in p.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            out[name] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[bytes/lane\])?: (\d+)", line)
+        if m and name:
+            out[name][m.group(1).strip()] = int(m.group(2))
+    return out
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")
+def test_hot_kernels_use_no_scratch():
+    from concurrent.futures import ThreadPoolExecutor
+
+    sources = ["mz_kernels.hip", "mz_conv3r.hip", "mz_conv3q.hip"]
+    with ThreadPoolExecutor(max_workers=3) as ex:  # three hipcc processes side by side: ~2 minutes in total
+        usages = dict(zip(sources, ex.map(resource_usage, sources)))
+    for src, usage in usages.items():
+        hot = {k: v for k, v in usage.items() if any(h in k for h in HOT) and ("TBF16" in k or "TF16" in k) and not any(e.search(k) for e in EXEMPT)}
+        assert hot, f"no hot kernel found in {src}: {list(usage)[:5]}"
+        bad = {k: v for k, v in hot.items() if v.get("ScratchSize", 0) != 0 or v.get("VGPRs Spill", 0) != 0}
+        assert not bad, "kernels with scratch memory / spilled VGPRs: " + ", ".join(f"{k}: {v}" for k, v in bad.items())
+        for k, v in hot.items():
+            if "conv3r_kernel" in k or "conv3q_kernel" in k:
+                assert v.get("Occupancy", v.get("Occupancy [waves/SIMD]", 2)) >= 2, f"{k}: two waves per SIMD are the design"

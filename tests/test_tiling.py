@@ -67,3 +67,22 @@ def test_tiled_4x_model_equals_untiled():
     m = m.to("cuda", torch.float16).eval()
     x = synth_image(1, 171, 232, seed=14).to("cuda", torch.float16)
     assert torch.equal(upscale_tiled(m, x, tile=(80, 80)), m.upscale(x))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["g2_odd_135x240", "g7_cfg1_2x_c48"])
+def test_tiled_upscale_against_the_reference_fixtures(name):
+    """N4 against the REFERENCE's own outputs (not against the untiled HIP result): `upscale_tiled` of the fixture's input in fp32
+    must meet the fixture within the north_star tolerance (1e-3 max-abs).  g2: odd sizes (floors and zero pads at every level) cut
+    into 64 x 96 tiles; g7: the BASELINE configs[0] model (48 channels / 20 layers) on 256 x 256, sampled fixture."""
+    case = GoldenCase(name)
+    m = MewZoom(**case.config)
+    m.load_state_dict(case.weights())
+    m = m.to("cuda", torch.float32).eval()
+    x = case.image().to("cuda", torch.float32)
+    halo = receptive_field(case.config)
+    tile = (64, 96)
+    assert x.shape[-2] > tile[0] or x.shape[-1] > tile[1], "the image must really be cut"
+    up = upscale_tiled(m, x, tile=tile)
+    err = case.compare_sr(up, up)["up"]     # the clamped result against the reference's upscale()
+    assert err <= 1e-3, f"{name}: tiled fp32 upscale deviates from the reference fixture by {err:.3e} (halo {halo})"

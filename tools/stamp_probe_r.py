@@ -15,12 +15,22 @@ for (B, H, W, cin, cout, silu) in CASES:
     x = torch.randn(B, cin // 8, H, W, 8, device="cuda").to(dt)
     w = torch.randn(cout, cin, 3, 3) * 0.02
     out = alloc_act(B, cout, H, W, dt)
+    if silu == 2:  # fused conv2 + AdaptiveResidualMix
+        xin = torch.randn(B, cout // 8, H, W, 8, device="cuda").to(dt)
+        wm = (torch.randn(cout, 2 * cout, 1, 1) * 0.1).to("cuda", torch.float32).contiguous()
+        wd = w.to("cuda", torch.float32).contiguous()
     for _ in range(int(os.environ.get("REPS", "3"))):
-        op_conv(dt, 0, x, None, w, 0.0, out, B, H, W, cin, cout, silu=silu)
+        if silu == 2:
+            _ffi.check(_ffi.lib().mz_op_conv_mix(_ffi.dtype_code(dt), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(xin.data_ptr()), ctypes.c_void_p(wd.data_ptr()),
+                                                 ctypes.c_void_p(wm.data_ptr()), ctypes.c_float(0.3), ctypes.c_void_p(out.data_ptr()), B, H, W, cin, cout,
+                                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            torch.cuda.synchronize()
+        else:
+            op_conv(dt, 0, x, None, w, 0.0, out, B, H, W, cin, cout, silu=silu)
     buf = (ctypes.c_ulonglong * (16 * 64 * 8))()
     assert _ffi.lib().mz_debug_read(buf) == 0
     a = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)
-    print(f"== {H}x{W} {cin}->{cout} silu={silu}: ideal MFMA cycles per tile {cin // 32 * 324 * 16}, per step {cin // 32 * 324 * 16 // (2 * (cin // 32))}")
+    print(f"== {H}x{W} {cin}->{cout} silu={silu}: ideal MFMA cycles per tile {cin // 32 * 324 * 16}, per step of two {cin // 32 * 324 * 16 // (2 * (cin // 32))}")
     for wv in (0, 4):
         r = a[wv * 32: wv * 32 + 32]
         n = max(r[1], 1)

@@ -73,9 +73,10 @@ __device__ __forceinline__ uint32_t pack_f16(float a, float b) {
     // v_fma_mix* form (one rounding, straight to f16) in some instantiations and not in others, and two kernels
     // that must agree bit for bit (per-tile vs persistent, any batch size) then differ in the last f16 bit.
     asm("" : "+v"(a), "+v"(b));
-    uint16_t lo = __builtin_bit_cast(uint16_t, (_Float16)a);
-    uint16_t hi = __builtin_bit_cast(uint16_t, (_Float16)b);
-    return (uint32_t)lo | ((uint32_t)hi << 16);
+    // gfx950: ONE v_cvt_pk_f16_f32 (round to nearest even, as the two scalar conversions + a pack it replaces)
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_{a, b}, f16x2_));
 }
 
 // 4 consecutive channels <-> memory

@@ -8,7 +8,7 @@ the zero padding / index clamping at an artificial cut changes never reaches a k
 multiples of 8 so that the three stride-2 levels, their floors at odd sizes and the decoder's bottom/right zero
 padding (model.py:650-689) fall on the same pixels as in the whole image; cuts at the true image border keep the
 true border.  The kernels accumulate in an order that does not depend on where a pixel sits in its tensor, so
-tiled and untiled results agree bit for bit (tests/test_tiling_gpu.py)."""
+tiled and untiled results agree bit for bit, and the tiled fp32 result meets the reference's fixtures (tests/test_tiling.py)."""
 
 from __future__ import annotations
 
