@@ -20,6 +20,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 #define CHECK(x)                                                                          \
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(512) void mfma_loop(const u32x4* __restrict__ opera
     unsigned long long t0, r0, t1, r1;
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0)::"memory");
     float total = 0.f;
-    if constexpr (SHAPE == 16) {
+    if constexpr (SHAPE == 16 || SHAPE == 17) {  // 17: the same loop on v_mfma_f32_16x16x32_f16 (operands: random fp16)
         f32x4 acc[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -59,8 +60,12 @@ __global__ __launch_bounds__(512) void mfma_loop(const u32x4* __restrict__ opera
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]),
-                                                                            __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+                        if constexpr (SHAPE == 16)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]),
+                                                                                __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[i]),
+                                                                               __builtin_bit_cast(f16x8, b[j]), acc[i][j], 0, 0, 0);
             // keep the accumulators bounded without touching the matrix pipe's schedule: nothing here
         }
 #pragma unroll
@@ -112,6 +117,14 @@ static uint16_t random_bf16() {  // uniform in [-1, 1): sign, exponent and manti
     uint32_t u;
     memcpy(&u, &v, 4);
     return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+static uint16_t random_f16() {  // uniform in [-1, 1) as IEEE half (round to nearest even)
+    const float v = (float)(rng() >> 8) / 8388608.0f - 1.0f;
+    const _Float16 h = (_Float16)v;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
 }
 
 struct Result {
@@ -179,14 +192,24 @@ int main(int argc, char** argv) {
     if (run<16>(512, cus, ops, sink, clocks, iters, min_seconds, r16x2)) return 1;
     if (run<32>(256, cus, ops, sink, clocks, iters, min_seconds, r32x1)) return 1;
     if (run<32>(512, cus, ops, sink, clocks, iters, min_seconds, r32x2)) return 1;
+    // the fp16 shape of the same loop, on random fp16 operands (does the chip clock the two 16-bit types alike?)
+    for (auto& v : host)
+        for (int k = 0; k < 4; ++k) v[k] = (uint32_t)random_f16() | ((uint32_t)random_f16() << 16);
+    CHECK(hipMemcpy(ops, host.data(), n_ops * sizeof(u32x4), hipMemcpyHostToDevice));
+    Result h16x1, h16x2;
+    if (run<17>(256, cus, ops, sink, clocks, iters, min_seconds, h16x1)) return 1;
+    if (run<17>(512, cus, ops, sink, clocks, iters, min_seconds, h16x2)) return 1;
     const double best = std::max(std::max(r16x1.tflops, r16x2.tflops), std::max(r32x1.tflops, r32x2.tflops));
     printf("{\"device\": \"%s\", \"cus\": %d, \"operands\": \"uniform random bf16 in [-1,1), register resident\", "
            "\"min_seconds_per_variant\": %.1f, \"measured_peak_tflops\": %.1f, \"variants\": {"
            "\"16x16x32_1wave_per_simd\": {\"tflops\": %.1f, \"clock_mhz\": %.0f, \"seconds\": %.2f}, "
            "\"16x16x32_2waves_per_simd\": {\"tflops\": %.1f, \"clock_mhz\": %.0f, \"seconds\": %.2f}, "
            "\"32x32x16_1wave_per_simd\": {\"tflops\": %.1f, \"clock_mhz\": %.0f, \"seconds\": %.2f}, "
-           "\"32x32x16_2waves_per_simd\": {\"tflops\": %.1f, \"clock_mhz\": %.0f, \"seconds\": %.2f}}}\n",
+           "\"32x32x16_2waves_per_simd\": {\"tflops\": %.1f, \"clock_mhz\": %.0f, \"seconds\": %.2f}, "
+           "\"f16_16x16x32_1wave_per_simd\": {\"tflops\": %.1f, \"clock_mhz\": %.0f, \"seconds\": %.2f}, "
+           "\"f16_16x16x32_2waves_per_simd\": {\"tflops\": %.1f, \"clock_mhz\": %.0f, \"seconds\": %.2f}}}\n",
            prop.name, cus, min_seconds, best, r16x1.tflops, r16x1.clock_mhz, r16x1.seconds, r16x2.tflops, r16x2.clock_mhz,
-           r16x2.seconds, r32x1.tflops, r32x1.clock_mhz, r32x1.seconds, r32x2.tflops, r32x2.clock_mhz, r32x2.seconds);
+           r16x2.seconds, r32x1.tflops, r32x1.clock_mhz, r32x1.seconds, r32x2.tflops, r32x2.clock_mhz, r32x2.seconds, h16x1.tflops,
+           h16x1.clock_mhz, h16x1.seconds, h16x2.tflops, h16x2.clock_mhz, h16x2.seconds);
     return 0;
 }

@@ -7,7 +7,7 @@ import numpy as np, torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent)); sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tests"))
 from gpu_util import alloc_act, op_conv
 from ultrazoom_amd import _ffi
-dt = torch.bfloat16
+dt = {"bf16": torch.bfloat16, "f16": torch.float16}[os.environ.get("STAMP_DTYPE", "bf16")]
 CASES = [(3, 1080, 1920, 96, 192, 1), (3, 540, 960, 192, 384, 1), (3, 135, 240, 1536, 768, 0)]
 if os.environ.get("STAMP_CASES"): CASES = eval(os.environ["STAMP_CASES"])
 NAMES = {1: "plain step, chunk's first", 2: "plain step, later", 3: "epilogue step, chunk's first", 4: "epilogue step, later"}
@@ -30,11 +30,12 @@ for (B, H, W, cin, cout, silu) in CASES:
     buf = (ctypes.c_ulonglong * (16 * 64 * 8))()
     assert _ffi.lib().mz_debug_read(buf) == 0
     a = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)
-    print(f"== {H}x{W} {cin}->{cout} silu={silu}: ideal MFMA cycles per tile {cin // 32 * 324 * 16}, per step of two {cin // 32 * 324 * 16 // (2 * (cin // 32))}")
+    print(f"== [{os.environ.get('STAMP_DTYPE', 'bf16')}] {H}x{W} {cin}->{cout} silu={silu}: ideal MFMA cycles per tile {cin // 32 * 324 * 16}, per step of two {cin // 32 * 324 * 16 // (2 * (cin // 32))}")
     for wv in (0, 4):
         r = a[wv * 32: wv * 32 + 32]
         n = max(r[1], 1)
-        line = f"  wave {wv}: tiles {r[1]}, K loop {r[0] // n} cycles per tile, final epilogue {r[2]}"
+        clock = f", in-kernel clock {r[28] / r[29] * 100.0:.0f} MHz over {r[28]} cycles" if r[29] > 0 else ""
+        line = f"  wave {wv}: tiles {r[1]}, K loop {r[0] // n} cycles per tile, final epilogue {r[2]}{clock}"
         print(line)
         for c in (1, 2, 3, 4):
             k = max(r[20 + c], 1)

@@ -196,23 +196,31 @@ __device__ __forceinline__ int lane_now() {
     return l;
 }
 
-// v * sigmoid(v), one value: v_mul, v_exp, v_add, v_rcp, v_mul as inline asm (left to hipcc, the SLP vectoriser pairs the
-// multiplies and adds into v_pk_* again).  hipcc's hazard recogniser does not look inside inline asm: a VALU instruction that
-// reads the result of a transcendental one needs a wait state, hence the s_nop in front of the add and the final multiply.
-__device__ __forceinline__ float silu1(float v) {
-    float t, r;
-    asm("v_mul_f32 %0, 0xbfb8aa3b, %1" : "=v"(t) : "v"(v));
-    t = __builtin_amdgcn_exp2f(t);
-    asm("s_nop 0\n\tv_add_f32 %0, 1.0, %1" : "=v"(t) : "v"(t));
-    t = __builtin_amdgcn_rcpf(t);
-    asm("s_nop 0\n\tv_mul_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(t));
-    return r;
+// v * sigmoid(v) of TWO values, in place: v_mul, v_exp, v_add, v_rcp, v_mul each, as ONE inline-asm block with the two chains
+// interleaved.  Inline asm because hipcc's SLP vectoriser pairs the multiplies and adds into v_pk_* (7 x slower beside the
+// partner's MFMA stream); one block because hipcc's hazard recogniser does not look inside inline asm: a VALU instruction that
+// reads the result of a transcendental one needs ONE wait state, which the other chain's instruction provides (no s_nop).
+// The same operations in the same order as silu2() / sigmoidf_(): identical bits.
+__device__ __forceinline__ void silu_pair(float& a, float& b) {
+    float ta, tb;
+    asm("v_mul_f32 %2, 0xbfb8aa3b, %0\n\t"
+        "v_mul_f32 %3, 0xbfb8aa3b, %1\n\t"
+        "v_exp_f32 %2, %2\n\t"
+        "v_exp_f32 %3, %3\n\t"
+        "v_add_f32 %2, 1.0, %2\n\t"
+        "v_add_f32 %3, 1.0, %3\n\t"
+        "v_rcp_f32 %2, %2\n\t"
+        "v_rcp_f32 %3, %3\n\t"
+        "v_mul_f32 %0, %0, %2\n\t"
+        "v_mul_f32 %1, %1, %3"
+        : "+v"(a), "+v"(b), "=&v"(ta), "=&v"(tb));
 }
 
 }  // namespace r3
 
-// EPI: EPI_STORE (runtime a.silu), EPI_D2S, EPI_FUSEDMIX (needs NSEG = 3).
-template <class TT, int NSEG, int EPI>
+// EPI: EPI_STORE (SILU: with the activation), EPI_D2S, EPI_FUSEDMIX (needs NSEG = 3).  SILU is a template parameter: a run-time
+// branch around the activation made hipcc copy every value twice more on its way through the epilogue.
+template <class TT, int NSEG, int EPI, bool SILU>
 __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     using namespace r3;
     using S = Seg<NSEG>;
@@ -379,22 +387,22 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     // same operations in the same order as silu2() (identical bits), but no packed-f32 arithmetic -- v_pk_mul_f32 / v_pk_add_f32
     // issue 7 x slower while the SIMD's other wave streams MFMAs (tools/microbench/mb_coissue.hip: 40 cycles each against 9
     // for v_mul_f32 and 16 for v_exp_f32 / v_rcp_f32)
+    float q_a = 0.f, q_b = 0.f;  // an entry's even quarter, kept for the pack behind its odd quarter
     auto epi_quarter = [&](auto e_tag, auto j_tag, u32x4& o) __attribute__((always_inline)) {
         constexpr int E = decltype(e_tag)::value, j = decltype(j_tag)::value;
         constexpr int pf = E / NT, n = E % NT;
-        f32x4& fa = acc[pf][2 * n];
-        f32x4& fb = acc[pf][2 * n + 1];
-        const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, (float)fa[j]), __builtin_bit_cast(uint32_t, (float)fb[j]), false, false);
+        // (no write-back into the accumulator tuples: their elements die here, so the swap and the SiLU work on them in place)
+        const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, (float)acc[pf][2 * n][j]),
+                                                         __builtin_bit_cast(uint32_t, (float)acc[pf][2 * n + 1][j]), false, false);
         const uint32_t s0 = sw[0], s1 = sw[1];
         float va = __builtin_bit_cast(float, s0), vb = __builtin_bit_cast(float, s1);
-        if constexpr (EPI != EPI_D2S) {
-            if (a.silu) { va = silu1(va); vb = silu1(vb); }
-        }
-        fa[j] = va;
-        fb[j] = vb;
+        if constexpr (EPI == EPI_STORE && SILU) silu_pair(va, vb);
         if constexpr (j & 1) {
-            o[j >> 1] = pack_pair<TT>(f32x2{fa[j - 1], fa[j]});
-            o[2 + (j >> 1)] = pack_pair<TT>(f32x2{fb[j - 1], fb[j]});
+            o[j >> 1] = pack_pair<TT>(f32x2{q_a, va});
+            o[2 + (j >> 1)] = pack_pair<TT>(f32x2{q_b, vb});
+        } else {
+            q_a = va;
+            q_b = vb;
         }
     };
     auto epi_store = [&](auto e_tag, const u32x4& o) __attribute__((always_inline)) {
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
             unpack2r<TT>(f_xq[nf][0], xv[0], xv[1]);
             unpack2r<TT>(f_xq[nf][1], xv[2], xv[3]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[pf][nf][j] = xv[j] + a.mix_scale * sigmoidf_(acc[pf][nf][j]) * (zv[j] - xv[j]);
+            for (int j = 0; j < 4; ++j) acc[pf][nf][j] = blend_(xv[j], zv[j], acc[pf][nf][j], a.inv_mix_scale);
         }
     };
     auto entry_whole = [&](auto e_tag) __attribute__((always_inline)) {

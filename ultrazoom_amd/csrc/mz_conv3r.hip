@@ -7,22 +7,22 @@
 
 namespace mz {
 
-template <class TT, int NSEG, int EPI> static hipError_t r_launch(const ConvArgs& a, hipStream_t s) {
+template <class TT, int NSEG, int EPI, bool SILU = false> static hipError_t r_launch(const ConvArgs& a, hipStream_t s) {
     constexpr size_t lds = r3::Seg<NSEG>::lds_bytes(EPI == EPI_FUSEDMIX);
     static bool ready[16] = {};  // per device ordinal: the dynamic-LDS limit of this instantiation has been raised
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
     if (!ready[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3r_kernel<TT, NSEG, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)conv3r_kernel<TT, NSEG, EPI, SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         ready[dev] = true;
     }
-    hipLaunchKernelGGL((conv3r_kernel<TT, NSEG, EPI>), dim3(a.persist), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((conv3r_kernel<TT, NSEG, EPI, SILU>), dim3(a.persist), dim3(512), lds, s, a);
     return hipGetLastError();
 }
 template <class TT> static hipError_t r_epi(const ConvArgs& a, hipStream_t s) {
     switch (a.epi) {
-        case EPI_STORE: return r_launch<TT, MZ_R_NSEG, EPI_STORE>(a, s);
+        case EPI_STORE: return a.silu ? r_launch<TT, MZ_R_NSEG, EPI_STORE, true>(a, s) : r_launch<TT, MZ_R_NSEG, EPI_STORE, false>(a, s);
         case EPI_D2S: return r_launch<TT, MZ_R_NSEG, EPI_D2S>(a, s);
         case EPI_FUSEDMIX: return a.wmix16 ? r_launch<TT, 3, EPI_FUSEDMIX>(a, s) : hipErrorInvalidValue;  // wmix16: PackArgs::frag16 = 2
         default: return hipErrorInvalidValue;

@@ -115,6 +115,16 @@ __device__ __forceinline__ float sigmoidf_(float v) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
 }
 
+// AdaptiveResidualMix blend (model.py:833-837): x + sigmoid(alpha) sigmoid(beta) (z - x) with the scale folded into the reciprocal:
+// sigmoid(alpha) sigmoid(beta) = 1 / ((1 + e^-beta) / sigmoid(alpha)) = rcp(fma(e^-beta, inv_s, inv_s)), inv_s = 1 + e^-alpha.
+// Six instructions per value (v_mul, v_exp, v_fma, v_rcp, v_sub, v_fma) instead of eight: the blends run beside MFMA streams, where
+// the vector ALU is the scarce resource (tools/microbench/mb_coissue.hip).
+__device__ __forceinline__ float blend_(float x, float z, float beta, float inv_s) {
+    const float e = __builtin_amdgcn_exp2f(beta * -1.4426950408889634f);
+    const float w = __builtin_amdgcn_rcpf(__builtin_fmaf(e, inv_s, inv_s));
+    return __builtin_fmaf(w, z - x, x);
+}
+
 // ---- one K-chunk of matrix work: acc[n][pixel] += W[n][k] * X[pixel][k] ------------------------
 // one 16-byte plane entry (8 channels of a 16-bit type, 4 of f32) <-> floats
 template <class TT> __device__ __forceinline__ void ld_unit(const void* p, float* v) {

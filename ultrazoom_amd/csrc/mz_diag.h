@@ -3,7 +3,11 @@
 // (MZ_DEBUG_STAMPS=1 allocates it; mz_debug_read() copies it out; tools/stamp_probe_r.py prints it).
 #pragma once
 #ifdef MZ_DIAG
-#define RS_DECL uint32_t rs_[32] = {}; uint32_t rs_t0 = 0, rs_t1 = 0
+#define RS_DECL                                                                                              \
+    uint32_t rs_[32] = {};                                                                                   \
+    uint32_t rs_t0 = 0, rs_t1 = 0;                                                                           \
+    unsigned long long rs_c0, rs_r0;                                                                         \
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(rs_c0), "=s"(rs_r0)::"memory")
 #define RS_NOW(v)                                                                         \
     do {                                                                                  \
         unsigned long long t__;                                                           \
@@ -21,6 +25,10 @@
 #define RS_COUNT(i) do { rs_[i] += 1; } while (0)
 #define RS_DUMP()                                                                                              \
     do {                                                                                                       \
+        unsigned long long rs_c1, rs_r1;                                                                       \
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(rs_c1), "=s"(rs_r1)::"memory"); \
+        rs_[28] = (uint32_t)(rs_c1 - rs_c0); /* shader-clock cycles of this wave's life */                         \
+        rs_[29] = (uint32_t)(rs_r1 - rs_r0); /* the same in 100 MHz ticks */                                       \
         if (a.dbg && blockIdx.x == gridDim.x / 2 && (threadIdx.x & 63) == 0) {                                               \
             _Pragma("unroll") for (int i__ = 0; i__ < 32; ++i__) a.dbg[w * 32 + i__] = rs_[i__];              \
         }                                                                                                      \

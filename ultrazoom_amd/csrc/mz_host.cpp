@@ -704,6 +704,8 @@ struct Runner {
                 a.x_via_lds = (a.mix_pieces * 1024 + 8 * ncx * 1024 <= 2 * slot) ? 1 : 0;
             }
             a.mix_scale = 1.0f / (1.0f + std::exp(-alpha));
+        a.inv_mix_scale = 1.0f + std::exp(-alpha);
+            a.inv_mix_scale = 1.0f + std::exp(-alpha);
             extra_flops = 2.0 * (double)B * H * W * 2.0 * c.cout * c.cout;
         }
         const double sz = dtype_size(dtype);
@@ -817,6 +819,7 @@ struct Runner {
         a.cp_out = pad16(c.cout);
         a.p_out = a.cp_out * sz / 16;
         a.mix_scale = 1.0f / (1.0f + std::exp(-alpha));
+        a.inv_mix_scale = 1.0f + std::exp(-alpha);
         const bool mix16 = c.packed16 != nullptr && knobs.mix16 &&
                            (double)npix * c.cp0 * sz < 4294967296.0;  // 32-bit buffer offsets inside each tensor
         if (mix16) {  // 192-channel N tiles, x / z straight into MFMA operands (mix16_kernel)

@@ -64,6 +64,7 @@ struct ConvArgs {
     int cp_out;        // STORE/MIX: padded channels of out; D2S: channels per output pixel (cq_p)
     int Hout, Wout;    // D2S / FINAL target grid
     float mix_scale;   // sigmoid(alpha)
+    float inv_mix_scale;  // 1 / sigmoid(alpha) = 1 + exp(-alpha): blend_() folds the scale into the reciprocal of the gate's sigmoid
     int R;             // FINAL: total upscale ratio of img -> out
     int Hi, Wi;        // FINAL: img size
     int clamp;

@@ -327,7 +327,7 @@ __device__ __forceinline__ void store_epilogue(const ConvArgs& a, f32x16 (&acc)[
                         ld_unit<TT>((const char*)a.in0 + (((long long)bimg * a.p0 + plane) * hwo + pix) * 16, xv);
                         ld_unit<TT>((const char*)a.in1 + (((long long)bimg * a.p1 + plane) * hwo + pix) * 16, zv);
 #pragma unroll
-                        for (int j = 0; j < PPU; ++j) v[j] = xv[j] + a.mix_scale * sigmoidf_(v[j]) * (zv[j] - xv[j]);
+                        for (int j = 0; j < PPU; ++j) v[j] = blend_(xv[j], zv[j], v[j], a.inv_mix_scale);
                     }
                     dst = obase + plane * plane_o + pix * 16;
                 }
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(576, 3) void conv3w_kernel(const ConvArgs a) {
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        beta[nt][4 * q + j] = xv[j] + a.mix_scale * sigmoidf_(beta[nt][4 * q + j]) * (zv[j] - xv[j]);
+                        beta[nt][4 * q + j] = blend_(xv[j], zv[j], beta[nt][4 * q + j], a.inv_mix_scale);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
@@ -1478,7 +1478,7 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
                     unpack2<TT>(xq[nf].y, xv[2], xv[3]);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[pf][nf][j] = xv[j] + a.mix_scale * sigmoidf_(acc[pf][nf][j]) * (zv[j] - xv[j]);
+                        acc[pf][nf][j] = blend_(xv[j], zv[j], acc[pf][nf][j], a.inv_mix_scale);
                 }
                 store_frag16<TT, NT, MODE, EPI_STORE, false>(a, acc[pf], pf, lane, w, nbase, b, y0, x0);
             }
@@ -1656,7 +1656,7 @@ __global__ __launch_bounds__(576) void mix16_kernel(const ConvArgs a) {
                 unpack2<TT>(zq[0], zv[0], zv[1]); unpack2<TT>(zq[1], zv[2], zv[3]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[pf][nf][j] = xv[j] + a.mix_scale * sigmoidf_(acc[pf][nf][j]) * (zv[j] - xv[j]);
+                    acc[pf][nf][j] = blend_(xv[j], zv[j], acc[pf][nf][j], a.inv_mix_scale);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
