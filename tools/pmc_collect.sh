@@ -7,8 +7,8 @@ OUT=$R/gpurun_out/${1:-pmc}
 WL=${2:-cfg3_1080p}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-microbench --images-per-gpu 3 --workload $WL"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-microbench --workload $WL > $OUT/stats.log 2>&1
+CMD="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-microbench --no-secondary --images-per-gpu 3 --workload $WL"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-microbench --no-secondary --workload $WL > $OUT/stats.log 2>&1
 echo "stats rc=$?"
 run() { # name counters...
   local name=$1; shift
