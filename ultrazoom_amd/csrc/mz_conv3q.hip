@@ -242,8 +242,6 @@ __global__ __launch_bounds__(512) void conv3q_kernel(const ConvArgs a) {
         bool l_ok = true;
         const char* l_w = (const char*)a.wpk16 + (size_t)l_nt * nchunks * chunk_bytes + lane * 16;
         set_load_tile(l_mt);
-        // timing-only builds (WRONG results): -DQ_ABLATE_DMA = the loaders issue nothing inside the loop;
-        // -DQ_ABLATE_WAIT = they do not wait for their loads before the barrier
         auto issue_halo = [&](char* dst) __attribute__((always_inline)) {
             if (!l_ok) return;
             const int planes = a.p0 - 4 * l_kc < 4 ? a.p0 - 4 * l_kc : 4;
@@ -292,32 +290,17 @@ __global__ __launch_bounds__(512) void conv3q_kernel(const ConvArgs a) {
         advance_load();
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-#if defined(Q_ABLATE_DMA) || defined(Q_ABLATE_H)   // -DQ_ABLATE_H / -DQ_ABLATE_W: only the halo / only the weight loads are dropped
-#define Q_ISSUE_H(x) do { } while (0)
-#else
-#define Q_ISSUE_H(x) x
-#endif
-#if defined(Q_ABLATE_DMA) || defined(Q_ABLATE_W)
-#define Q_ISSUE_W(x) do { } while (0)
-#else
-#define Q_ISSUE_W(x) x
-#endif
-#ifdef Q_ABLATE_WAIT
-#define Q_WAIT() do { } while (0)
-#else
-#define Q_WAIT() wait_vmcnt<0>()
-#endif
         for (int h = 0; h < nhalf; h += 2) {
             // first half of a chunk: the NEXT chunk's halo image and first weight half
-            Q_ISSUE_H(issue_halo(hal_nxt));
-            Q_ISSUE_W(issue_weights(0, ws_nn));
-            Q_WAIT();
+            issue_halo(hal_nxt);
+            issue_weights(0, ws_nn);
+            wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             { char* t_ = ws_cur; ws_cur = ws_nxt; ws_nxt = ws_nn; ws_nn = t_; }
             // second half: the next chunk's second weight half
-            Q_ISSUE_W(issue_weights(1, ws_nn));
+            issue_weights(1, ws_nn);
             advance_load();
-            Q_WAIT();
+            wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             { char* t_ = ws_cur; ws_cur = ws_nxt; ws_nxt = ws_nn; ws_nn = t_; }
             { char* t_ = hal_cur; hal_cur = hal_nxt; hal_nxt = t_; }

@@ -161,16 +161,6 @@ template <class TT> __device__ __forceinline__ void st_unit(void* p, const float
 
 template <class TT> __device__ __forceinline__ void mma(f32x16& acc, const u32x4& w, const u32x4& x);
 template <> __device__ __forceinline__ void mma<TBF16>(f32x16& acc, const u32x4& w, const u32x4& x) {
-#if defined(MZ_ABLATE) && (MZ_ABLATE & 128)
-    // timing-only (WRONG results): the same FLOPs as two v_mfma_f32_16x16x32_bf16, to price that shape's clock in situ
-    typedef float f32x4_ __attribute__((ext_vector_type(4)));
-    f32x4_ q0 = __builtin_shufflevector(acc, acc, 0, 1, 2, 3), q1 = __builtin_shufflevector(acc, acc, 4, 5, 6, 7);
-    q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x), q0, 0, 0, 0);
-    q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x), q1, 0, 0, 0);
-    acc[0] = q0[0]; acc[1] = q0[1]; acc[2] = q0[2]; acc[3] = q0[3];
-    acc[4] = q1[0]; acc[5] = q1[1]; acc[6] = q1[2]; acc[7] = q1[3];
-    return;
-#endif
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x),
                                                   acc, 0, 0, 0);
 }

@@ -553,7 +553,7 @@ extern "C" int mz_workspace_bytes(const mz_handle* h, int B, int H, int W, int m
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
-// Diagnostic stamp buffer (only -DMZ_STAMP kernel builds write to it; MZ_DEBUG_STAMPS=1 allocates it).
+// Diagnostic stamp buffer (only -DMZ_DIAG kernel builds write to it, mz_diag.h; MZ_DEBUG_STAMPS=1 allocates it).
 static unsigned long long* debug_buffer() {
     static unsigned long long* buf = nullptr;
     static bool tried = false;

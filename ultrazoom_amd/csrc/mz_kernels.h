@@ -77,7 +77,7 @@ struct ConvArgs {
     const float* film_gamma;  // EPI_STORE on conv3s_kernel only: per-image per-channel affine gamma * y + beta ahead of the SiLU
     const float* film_beta;   //   (float [B][cp_out], pad channels zero); nullptr = off.  No reference counterpart.
     int use_glds;      // stage through global_load_lds (1) or through registers (0)
-    unsigned long long* dbg;  // -DMZ_STAMP diagnostic builds: per-stage s_memtime stamps of one workgroup
+    unsigned long long* dbg;  // -DMZ_DIAG builds (mz_diag.h): cycle counters of one workgroup of conv3r_kernel
 };
 
 size_t conv_lds_bytes(int mode, int nt);

@@ -38,11 +38,6 @@ static constexpr bool kGlds = false;
 #else
 static constexpr bool kGlds = true;
 #endif
-// -DMZ_ABLATE=<mask> builds timing-only variants (WRONG results) used to price the parts of the main loop:
-//   1 no LDS-DMA staging inside the loop, 2 no vmcnt/barrier at the end of a stage, 4 no fragment reads.
-#ifndef MZ_ABLATE
-#define MZ_ABLATE 0
-#endif
 #ifndef MZ_GEMM1_S
 #define MZ_GEMM1_S 2  // K-chunks per stage of the 1x1 kernel: 44 KiB of LDS -> 3 workgroups per CU (measured best of 1..4)
 #endif
@@ -115,7 +110,7 @@ __device__ __forceinline__ void mfma_steps(f32x16 (&acc)[2][NT], const Frags<NT>
     if constexpr (M < 2 * NT) {
         mma<TT>(acc[M & 1][M >> 1], cur.w[M >> 1], (M & 1) ? cur.x1 : cur.x0);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (ITEM + 1 < NITEMS && !(MZ_ABLATE & 4)) {
+        if constexpr (ITEM + 1 < NITEMS) {
             issue_read<NT, MODE, ITEM + 1, 2 * M>(nxt, a_addr, b_addr);
             issue_read<NT, MODE, ITEM + 1, 2 * M + 1>(nxt, a_addr, b_addr);
             if constexpr (M == 2 * NT - 1) {  // NT == 1: 3 reads, 2 MFMAs
@@ -133,11 +128,8 @@ __device__ __forceinline__ void run_items(f32x16 (&acc)[2][NT], Frags<NT>& cur, 
     if constexpr (ITEM < NITEMS) {
         __builtin_amdgcn_sched_barrier(0);
         mfma_steps<TT, NT, MODE, ITEM, NITEMS, 0>(acc, cur, nxt, a_addr, b_addr);
-        if constexpr (ITEM + 1 < NITEMS && !(MZ_ABLATE & 4)) wait_frags<NT>(nxt);
-        if constexpr (MZ_ABLATE & 4)
-            run_items<TT, NT, MODE, ITEM + 1, NITEMS>(acc, cur, nxt, a_addr, b_addr);
-        else
-            run_items<TT, NT, MODE, ITEM + 1, NITEMS>(acc, nxt, cur, a_addr, b_addr);
+        if constexpr (ITEM + 1 < NITEMS) wait_frags<NT>(nxt);
+        run_items<TT, NT, MODE, ITEM + 1, NITEMS>(acc, nxt, cur, a_addr, b_addr);
     }
 }
 
@@ -378,20 +370,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const int epi, 
 //     from HBM as plain 16-byte loads (plane-major layout), and the gate weights are prefetched by the loader
 //     wave into ring slots 1-2 while the last K-stage is being computed.
 // ================================================================================================
-// -DMZ_STAMP=2: diagnostic build that records where one workgroup's waves spend each K-stage (never shipped);
-// -DMZ_STAMP=1 only records the in-kernel clock probe.
-#if defined(MZ_STAMP) && MZ_STAMP >= 2
-#define STAMP(k)                                                                                                  \
-    do {                                                                                                          \
-        if (a.dbg && blockIdx.x == gridDim.x / 2 && st < 64 && lane == 0) {                                        \
-            unsigned long long t_;                                                                                \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                            \
-            a.dbg[((w * 64) + st) * 8 + (k)] = t_;                                                                \
-        }                                                                                                         \
-    } while (0)
-#else
-#define STAMP(k) do { } while (0)
-#endif
 
 // z accumulators -> MFMA B-operand fragments, and back to the (rounded) values for the blend
 template <class TT> struct ZFrag;
@@ -485,12 +463,9 @@ __global__ __launch_bounds__(576, 3) void conv3w_kernel(const ConvArgs a) {
         sl = sl == 2 ? 0 : sl + 1;  // slot of stage st + 2
         const int mix1 = FUSE ? (a.mix_pieces < SLOT / 1024 ? a.mix_pieces : SLOT / 1024) : 0;  // pieces that fit slot 1
         for (int st = 0; st < nstages; ++st) {
-            STAMP(0);
             if (st + 1 < nstages) wait_vmcnt<B_PIECES>(); else wait_vmcnt<0>();
-            STAMP(1);
             __builtin_amdgcn_s_barrier();
-            STAMP(2);
-            if (st + 2 < nstages && !(MZ_ABLATE & 16)) loadB(st + 2, sl);
+            if (st + 2 < nstages) loadB(st + 2, sl);
             if (FUSE) {
                 const char* msrc = (const char*)a.wmix + lane * 16;
                 if (st == (last > 0 ? last - 1 : 0))  // slot 1 was last read in stage last-2: free after this barrier
@@ -498,7 +473,6 @@ __global__ __launch_bounds__(576, 3) void conv3w_kernel(const ConvArgs a) {
                 if (st == last)                       // slot 2 was last read in stage last-1
                     for (int j = mix1; j < a.mix_pieces; ++j) glds16(msrc + j * 1024, mixw + j * 1024);
             }
-            STAMP(3);
             sl = sl == 2 ? 0 : sl + 1;
         }
         wait_vmcnt<0>();
@@ -545,14 +519,6 @@ __global__ __launch_bounds__(576, 3) void conv3w_kernel(const ConvArgs a) {
     sl2 = sl2 == 2 ? 0 : sl2 + 1;
     if (nstages > 1) loadA(1, sl2);
     sl2 = sl2 == 2 ? 0 : sl2 + 1;  // slot of stage st + 2
-#ifdef MZ_STAMP
-    if (a.dbg && w == 0 && lane == 0 && (blockIdx.x & 255) == 7) {  // clock probe: shader cycles vs 100 MHz real time
-        unsigned long long t_, r_;
-        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_)::"memory");
-        a.dbg[(15 * 64 + (blockIdx.x >> 8) % 60) * 8 + 0] = t_;
-        a.dbg[(15 * 64 + (blockIdx.x >> 8) % 60) * 8 + 1] = r_;
-    }
-#endif
 
     f32x16 acc[2][NT];
 #pragma unroll
@@ -591,18 +557,14 @@ __global__ __launch_bounds__(576, 3) void conv3w_kernel(const ConvArgs a) {
 
     for (int st = 0; st < nstages; ++st) {
         // my own activation DMA of stage st has landed once at most the newer stage's instructions are pending
-        STAMP(0);
         if (st + 1 < nstages) {
             if (nA == 3) wait_vmcnt<3>(); else wait_vmcnt<2>();
         } else {
             wait_vmcnt<0>();
         }
-        STAMP(1);
         __builtin_amdgcn_s_barrier();  // stage st is complete in LDS; everyone is done reading stage st-1
-        STAMP(2);
-        if (st + 2 < nstages && !(MZ_ABLATE & 8)) loadA(st + 2, sl2);
+        if (st + 2 < nstages) loadA(st + 2, sl2);
         if (FUSE && st == last && a.x_via_lds) x_dma(0);  // slots 1-2 are free from here on; lands under this stage's MFMAs
-        STAMP(3);
 
         const uint32_t a_addr = a_lane + slot * SLOT;
         const uint32_t b_addr = b_lane + slot * SLOT;
@@ -610,20 +572,11 @@ __global__ __launch_bounds__(576, 3) void conv3w_kernel(const ConvArgs a) {
         issue_reads<NT, MODE, 0>(fa, a_addr, b_addr);
         wait_frags<NT>(fa);
         run_items<TT, NT, MODE, 0, 9>(acc, fa, fb, a_addr, b_addr);
-        STAMP(4);
         slot = slot == 2 ? 0 : slot + 1;
         sl2 = sl2 == 2 ? 0 : sl2 + 1;
     }
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // all fragment reads are done (and, FUSE, the gate weights have landed)
-#ifdef MZ_STAMP
-    if (a.dbg && w == 0 && lane == 0 && (blockIdx.x & 255) == 7) {
-        unsigned long long t_, r_;
-        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_)::"memory");
-        a.dbg[(15 * 64 + (blockIdx.x >> 8) % 60) * 8 + 2] = t_;
-        a.dbg[(15 * 64 + (blockIdx.x >> 8) % 60) * 8 + 3] = r_;
-    }
-#endif
 
     constexpr int EPW = 32 * (BN * SZ + 16) > 32 * 80 ? 32 * (BN * SZ + 16) : 32 * 80;
     const long long em[2] = {0, 0};
@@ -1138,19 +1091,6 @@ __device__ __forceinline__ void store_epilogue16(const ConvArgs& a, f32x4 (&acc)
     for (int pf = 0; pf < 4; ++pf) store_frag16<TT, NT, MODE, EPI, SILU, FILM>(a, acc[pf], pf, lane, w, nbase, b, y0, x0);
 }
 
-// -DMZ_STAMP=2 diagnostic build: where the waves of one workgroup spend each half-chunk (tools/stamp_probe16.py)
-#if defined(MZ_STAMP) && MZ_STAMP >= 2
-#define S16STAMP(u, k)                                                                                            \
-    do {                                                                                                          \
-        if (a.dbg && blockIdx.x == gridDim.x / 2 && (u) < 64 && lane == 0) {                                       \
-            unsigned long long t_;                                                                                \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                            \
-            a.dbg[((w * 64) + (u)) * 8 + (k)] = t_;                                                               \
-        }                                                                                                         \
-    } while (0)
-#else
-#define S16STAMP(u, k) do { } while (0)
-#endif
 // gate GEMM of the fused mix on the 16x16 layout: 2 NT K-steps of NF = 2 NT weight fragments each, walked in HALF
 // steps of NT fragments: the next half step's fragments are requested before the current one's MFMAs are issued
 // (LDS reads return in order: lgkmcnt(NT) = "everything but the NT reads just requested has landed").
@@ -1288,13 +1228,9 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
             int u = 0;
             for (int t = 0; t < ntl; ++t) {
                 for (int hh = 0; hh < 2 * nchunks; ++hh, ++u) {
-                    S16STAMP(u, 0);
                     wait_vmcnt<0>();
-                    S16STAMP(u, 1);
                     __builtin_amdgcn_s_barrier();
-                    S16STAMP(u, 2);
                     issue();
-                    S16STAMP(u, 3);
                 }
                 if constexpr (FUSE) {
                     __builtin_amdgcn_s_barrier();  // E1: every wave has left the K loop: the second weight slot is free
@@ -1354,13 +1290,9 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
             int u = 0;
             for (int t = 0; t < ntl; ++t) {
                 for (int hh = 0; hh < 2 * nchunks; ++hh, ++u) {
-                    S16STAMP(u, 0);
                     if ((hh & 1) == 0) wait_vmcnt<0>();  // a chunk's first barrier publishes its halo image
-                    S16STAMP(u, 1);
                     __builtin_amdgcn_s_barrier();
-                    S16STAMP(u, 2);
                     if ((hh & 1) == 0) issue();          // chunk c + 1 -> the slot chunk c - 1 was read from
-                    S16STAMP(u, 3);
                 }
                 if constexpr (FUSE) {
                     __builtin_amdgcn_s_barrier();  // E1
@@ -1378,9 +1310,6 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
     const uint32_t b_lane = lds_base + B_BASE + lane * 16;
     uint32_t a_cur = a_lane, a_oth = a_lane + A_SLOT;  // this lane's address in the current / the other halo image
     Frag16 f;
-#if defined(MZ_STAMP) && MZ_STAMP >= 2
-    int ustamp = 0;  // chunks done by this workgroup
-#endif
     while (cur < cnt) {
         int b, y0, x0;
         tile_origin(mtile, b, y0, x0);
@@ -1390,24 +1319,10 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) acc[pf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int kc = 0; kc < nchunks; ++kc) {
-            S16STAMP(ustamp, 0);
             __builtin_amdgcn_s_barrier();
-            S16STAMP(ustamp, 1);
-#if MZ_ABLATE & 512  // timing-only: the younger wave of every SIMD does no matrix work (what does ONE wave per SIMD sustain?)
-            if (w < 4)
-#endif
             s16_front<TT, NT, MODE>(acc, f, a_cur, b_lane);
-            S16STAMP(ustamp, 2);
             __builtin_amdgcn_s_barrier();
-            S16STAMP(ustamp, 3);
-#if MZ_ABLATE & 512
-            if (w < 4)
-#endif
             s16_back<TT, NT, MODE>(acc, f, a_cur, b_lane);
-            S16STAMP(ustamp, 4);
-#if defined(MZ_STAMP) && MZ_STAMP >= 2
-            ++ustamp;
-#endif
             const uint32_t tmp = a_cur; a_cur = a_oth; a_oth = tmp;
         }
         const int nbase = ntile * BN;
@@ -1765,7 +1680,6 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
         const int npieces = B_PIECES;  // GEMM1: nchunks is padded to a multiple of S with zero weights
         const char* wsrc = wtile + (size_t)kc0 * (TAPS * NT * 1024);
         for (int j = w; j < npieces; j += 4) {
-            if ((MZ_ABLATE & 16) && st > 0) break;  // timing-only: no weight staging inside the loop
             if (kGlds) {
                 glds16(wsrc + j * 1024 + lane * 16, Bbuf + j * 1024);
             } else {
@@ -1773,7 +1687,6 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
             }
         }
         // ---- activations ----
-        if ((MZ_ABLATE & 8) && st > 0) return;  // timing-only: no activation staging inside the loop
         if (MODE == MODE_CONV3) {
             const long long kbyte = 2LL * kc0 * plane_in;  // a K-chunk = two planes
 #pragma unroll
@@ -1836,7 +1749,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
 
     for (int st = 0; st < nstages; ++st) {
         const int cur = st & 1;
-        if (st + 1 < nstages && !(MZ_ABLATE & 1)) stage_load(st + 1, cur ^ 1);
+        if (st + 1 < nstages) stage_load(st + 1, cur ^ 1);
 
         const uint32_t a_addr = lds_base + cur * STAGE + a_lane;
         const uint32_t b_addr = lds_base + cur * STAGE + A_BYTES + lane * 16;
@@ -1844,10 +1757,8 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
         issue_reads<NT, MODE, 0>(fa, a_addr, b_addr);
         wait_frags<NT>(fa);
         run_items<TT, NT, MODE, 0, TAPS * S>(acc, fa, fb, a_addr, b_addr);
-        if (!(MZ_ABLATE & 2)) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
 
     // ============================== epilogue ==============================
