@@ -90,7 +90,7 @@ struct Bases {
 // weight pair of group GC + 2 and (n < 2) three pixel fragments of tap t + 1 -- from the NEXT slot / halo image where the
 // group or tap index runs past this segment / chunk.  Tap t reads pixel buffer (t + XP) & 1 (a chunk has 9 taps, so the
 // parity of a chunk's tap 0 flips from chunk to chunk; XP = chunk index & 1 inside the tile).
-template <class TT, int NSEG, int GC, int XP, int M>
+template <class TT, int NSEG, int GC, int XP, bool ZERO_C, int M>
 __device__ __forceinline__ void group_mfmas(f32x4 (&acc)[NPF][NF], Frag& f, const Bases& bs) {
     if constexpr (M < 12) {
         using S = Seg<NSEG>;
@@ -101,7 +101,15 @@ __device__ __forceinline__ void group_mfmas(f32x4 (&acc)[NPF][NF], Frag& f, cons
         constexpr bool t_here = T < Ge;
         constexpr int t_idx = t_here ? T - Gs : T - Ge;  // its index inside its segment
         constexpr int k = M / 6, pf = M % 6;
-        mma16<TT>(acc[pf][2 * n + k], f.w[GC % 3][k], f.x[xp][pf]);
+        if constexpr (ZERO_C) {  // a tile's first tap WRITES the accumulators (C = 0): nobody has to clear 144 registers per tile
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (TT::IS_BF16)
+                acc[pf][2 * n + k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, f.w[GC % 3][k]), __builtin_bit_cast(bf16x8_t, f.x[xp][pf]), zero, 0, 0, 0);
+            else
+                acc[pf][2 * n + k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, f.w[GC % 3][k]), __builtin_bit_cast(f16x8_t, f.x[xp][pf]), zero, 0, 0, 0);
+        } else {
+            mma16<TT>(acc[pf][2 * n + k], f.w[GC % 3][k], f.x[xp][pf]);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (M < 2) {
             f.w[T % 3][M] = lds_read128<(2 * t_idx + M) * 1024>(t_here ? bs.b_cur : bs.b_nxt);
@@ -113,17 +121,22 @@ __device__ __forceinline__ void group_mfmas(f32x4 (&acc)[NPF][NF], Frag& f, cons
             else f.x[xq][pfn] = lds_read128<a_off<0, pfn>()>(bs.a_nxt);
             __builtin_amdgcn_sched_barrier(0);
         }
-        group_mfmas<TT, NSEG, GC, XP, M + 1>(acc, f, bs);
+        group_mfmas<TT, NSEG, GC, XP, ZERO_C, M + 1>(acc, f, bs);
     }
 }
 
 // groups [G, GE) of one step
 template <class TT, int NSEG, int G, int GE, int XP>
-__device__ __forceinline__ void groups(f32x4 (&acc)[NPF][NF], Frag& f, const Bases& bs) {
+__device__ __forceinline__ void groups(f32x4 (&acc)[NPF][NF], Frag& f, const Bases& bs, bool first) {
     if constexpr (G < GE) {
         constexpr int t = G / 3, n = G % 3;
         __builtin_amdgcn_sched_barrier(0);
-        group_mfmas<TT, NSEG, G, XP, 0>(acc, f, bs);
+        if constexpr (G < 3 && XP == 0) {  // tap 0 of a chunk that may be the tile's first (a tile starts on parity 0)
+            if (first) group_mfmas<TT, NSEG, G, XP, true, 0>(acc, f, bs);
+            else group_mfmas<TT, NSEG, G, XP, false, 0>(acc, f, bs);
+        } else {
+            group_mfmas<TT, NSEG, G, XP, false, 0>(acc, f, bs);
+        }
         // what the NEXT group needs (also across the end of this step: the stream continues behind the barrier).  LDS reads
         // return in order.  Reads requested per group: n = 0, 1: two weight + three pixel fragments, n = 2: two weight fragments.
         constexpr int wn = (G + 1) % 3, xn = (t + 1 + XP) & 1;
@@ -133,7 +146,7 @@ __device__ __forceinline__ void groups(f32x4 (&acc)[NPF][NF], Frag& f, const Bas
             wait_w<8>(f.w[wn][0], f.w[wn][1]);
         else
             wait_w<5>(f.w[wn][0], f.w[wn][1]);
-        groups<TT, NSEG, G + 1, GE, XP>(acc, f, bs);
+        groups<TT, NSEG, G + 1, GE, XP>(acc, f, bs, first);
     }
 }
 
@@ -599,7 +612,7 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
             if constexpr (last) {
                 // the epilogue is complete: clear the accumulators and prime the fragment stream for the next tile.  Unconditional
                 // on every path into the compute role, so that the fragment registers are DEAD throughout the loader role.
-                zero_acc();
+                if constexpr (FUSE) zero_acc();  // (with the tile's first tap writing the accumulators instead, hipcc spills in this variant)
                 prime(next3(hs), us ^ 1);
             } else {
                 if (k + 2 == nchunks && okB) {  // the next step requests tB's first halo image
@@ -713,14 +726,14 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
             const uint32_t u_ = b0; b0 = b1; b1 = b2; b2 = u_;
             bs.b_cur = b0; bs.b_nxt = b1;
         };
-        auto chunk = [&](auto xp_tag) __attribute__((always_inline)) {
+        auto chunk = [&](auto xp_tag, bool first) __attribute__((always_inline)) {
             constexpr int XP = decltype(xp_tag)::value;
-            groups<TT, NSEG, S::start(0), S::start(1), XP>(acc, f, bs);
+            groups<TT, NSEG, S::start(0), S::start(1), XP>(acc, f, bs, first);
             step_tail();
-            groups<TT, NSEG, S::start(1), S::start(2), XP>(acc, f, bs);
+            groups<TT, NSEG, S::start(1), S::start(2), XP>(acc, f, bs, false);
             step_tail();
             if constexpr (NSEG == 3) {
-                groups<TT, NSEG, S::start(2), S::start(3), XP>(acc, f, bs);
+                groups<TT, NSEG, S::start(2), S::start(3), XP>(acc, f, bs, false);
                 step_tail();
             }
             const uint32_t v_ = bs.a_cur; bs.a_cur = bs.a_nxt; bs.a_nxt = v_;
@@ -733,9 +746,9 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         RS_BEGIN();
         int kc = 0;
         for (;;) {
-            chunk(ic<0>{});
+            chunk(ic<0>{}, !FUSE && kc == 0);  // (the fused variant clears its accumulators in the helper role: see there)
             if (++kc >= nchunks) break;
-            chunk(ic<1>{});
+            chunk(ic<1>{}, false);
             if (++kc >= nchunks) break;
         }
         asm volatile("s_waitcnt lgkmcnt(0)"
@@ -802,13 +815,13 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         }
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();  // B_0
-        zero_acc();
+        if constexpr (FUSE) zero_acc();
         loader_phase(ic<0>{});
         advance();
         if (a_pos >= cnt) { RS_DUMP(); return; }
     } else {
         __builtin_amdgcn_s_barrier();  // B_0
-        zero_acc();
+        if constexpr (FUSE) zero_acc();
         prime(0, 0);
     }
     for (;;) {
