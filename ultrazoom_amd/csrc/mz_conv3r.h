@@ -13,7 +13,8 @@
 //     steps ahead -- near the end of the tile these already belong to tile i + 1),
 //   * finishes ITS OWN previous tile i - 1 out of its accumulators: SiLU / pack / stores, a few 16-byte entries per step,
 //     placed behind the step's DMA issue,
-//   * zeroes its accumulators and, in the tile's last step, primes its fragment registers for tile i + 1,
+//   * in the tile's last step primes its fragment registers for tile i + 1 (a tile's first tap WRITES the accumulators -- MFMA with
+//     C = 0 --, so nobody clears them; the fused variant, which spills with that, clears them here),
 // and at the tile boundary the teams swap.  The matrix pipe of a SIMD sees one uninterrupted K-loop stream; both register
 // files hold accumulators; a tile's K loop starts on a freshly primed wave, so odd chunk counts need no tap-parity carry.
 //
@@ -765,11 +766,6 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         us ^= nchunks & 1;
         done = Done{a_mt, a_nt};
     };
-    auto final_entry = [&](auto e_tag) __attribute__((always_inline)) {
-        u32x4 o;
-        epi_quarter(e_tag, ic<0>{}, o); epi_quarter(e_tag, ic<1>{}, o); epi_quarter(e_tag, ic<2>{}, o); epi_quarter(e_tag, ic<3>{}, o);
-        epi_store(e_tag, o);
-    };
     auto final_fuse_pf = [&](auto pf_tag) __attribute__((always_inline)) {
         constexpr int pf = decltype(pf_tag)::value;
         fuse_a(pf_tag);
@@ -782,9 +778,9 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         if constexpr (FUSE) {
             final_fuse_pf(ic<0>{}); final_fuse_pf(ic<1>{}); final_fuse_pf(ic<2>{}); final_fuse_pf(ic<3>{}); final_fuse_pf(ic<4>{}); final_fuse_pf(ic<5>{});
         } else {
-            final_entry(ic<0>{}); final_entry(ic<1>{}); final_entry(ic<2>{}); final_entry(ic<3>{}); final_entry(ic<4>{}); final_entry(ic<5>{});
-            final_entry(ic<6>{}); final_entry(ic<7>{}); final_entry(ic<8>{}); final_entry(ic<9>{}); final_entry(ic<10>{}); final_entry(ic<11>{});
-            final_entry(ic<12>{}); final_entry(ic<13>{}); final_entry(ic<14>{}); final_entry(ic<15>{}); final_entry(ic<16>{}); final_entry(ic<17>{});
+            entry_whole(ic<0>{}); entry_whole(ic<1>{}); entry_whole(ic<2>{}); entry_whole(ic<3>{}); entry_whole(ic<4>{}); entry_whole(ic<5>{});
+            entry_whole(ic<6>{}); entry_whole(ic<7>{}); entry_whole(ic<8>{}); entry_whole(ic<9>{}); entry_whole(ic<10>{}); entry_whole(ic<11>{});
+            entry_whole(ic<12>{}); entry_whole(ic<13>{}); entry_whole(ic<14>{}); entry_whole(ic<15>{}); entry_whole(ic<16>{}); entry_whole(ic<17>{});
         }
     };
 
