@@ -55,9 +55,8 @@ template <int NSEG> struct Seg {
     static constexpr int of(int G) { return NSEG == 2 ? (G < start(1) ? 0 : 1) : G / (NG / 3); }
     static constexpr int pieces(int s) { return 2 * (start(s + 1) - start(s)); }
     static constexpr int SLOT = pieces(0) * 1024;  // the largest segment is the first
-    static constexpr int AOFF_BASE = B_BASE + 3 * SLOT;  // plain variants, 8 KB: halo offsets handed from team to team (4 waves x 8 pieces x 64 lanes)
     static constexpr int MIX_BASE = B_BASE + 3 * SLOT;   // fused variant, 36 KB: the gate weights (instead of the hand-off table)
-    static constexpr int lds_bytes(bool fuse) { return fuse ? MIX_BASE + MIX_PIECES * 1024 : AOFF_BASE + 8192; }
+    static constexpr int lds_bytes(bool fuse) { return fuse ? MIX_BASE + MIX_PIECES * 1024 : B_BASE + 3 * SLOT; }
 };
 
 // byte offset of pixel fragment pf of tap (dy, dx) inside one plane of the halo image, relative to the wave's first row
@@ -229,6 +228,44 @@ __device__ __forceinline__ void silu_pair(float& a, float& b) {
         "v_mul_f32 %1, %1, %3"
         : "+v"(a), "+v"(b), "=&v"(ta), "=&v"(tb));
 }
+// The same, OUT of place (the inputs stay untouched: accumulator elements need no copy into scratch registers first; the results
+// double as the chains' temporaries)
+__device__ __forceinline__ void silu_pair_to(float& ra, float& rb, const float a, const float b) {
+    asm("v_mul_f32 %0, 0xbfb8aa3b, %2\n\t"
+        "v_mul_f32 %1, 0xbfb8aa3b, %3\n\t"
+        "v_exp_f32 %0, %0\n\t"
+        "v_exp_f32 %1, %1\n\t"
+        "v_add_f32 %0, 1.0, %0\n\t"
+        "v_add_f32 %1, 1.0, %1\n\t"
+        "v_rcp_f32 %0, %0\n\t"
+        "v_rcp_f32 %1, %1\n\t"
+        "v_mul_f32 %0, %2, %0\n\t"
+        "v_mul_f32 %1, %3, %1"
+        : "=&v"(ra), "=&v"(rb)
+        : "v"(a), "v"(b));
+}
+
+// x + sigmoid(alpha) sigmoid(beta) (z - x) of TWO values, out of place: blend_()'s operations in blend_()'s order
+// (mz_device.h: v_mul, v_exp, v_fma, v_rcp, v_sub, v_fma; identical bits), as one inline-asm block of two interleaved chains for the
+// same reasons as silu_pair() -- left to hipcc, the SLP vectoriser pairs the adds and fmas into v_pk_add_f32 / v_pk_fma_f32.
+__device__ __forceinline__ void blend_pair_to(float& o0, float& o1, const float b0, const float b1, const float x0, const float x1,
+                                              const float z0, const float z1, const float inv_s) {
+    float d0, d1;
+    asm("v_mul_f32 %0, 0xbfb8aa3b, %4\n\t"
+        "v_mul_f32 %1, 0xbfb8aa3b, %5\n\t"
+        "v_exp_f32 %0, %0\n\t"
+        "v_exp_f32 %1, %1\n\t"
+        "v_fma_f32 %0, %0, %10, %10\n\t"
+        "v_fma_f32 %1, %1, %10, %10\n\t"
+        "v_rcp_f32 %0, %0\n\t"
+        "v_rcp_f32 %1, %1\n\t"
+        "v_sub_f32 %2, %8, %6\n\t"
+        "v_sub_f32 %3, %9, %7\n\t"
+        "v_fma_f32 %0, %0, %2, %6\n\t"
+        "v_fma_f32 %1, %1, %3, %7"
+        : "=&v"(o0), "=&v"(o1), "=&v"(d0), "=&v"(d1)
+        : "v"(b0), "v"(b1), "v"(x0), "v"(x1), "v"(z0), "v"(z1), "s"(inv_s));
+}
 
 }  // namespace r3
 
@@ -292,7 +329,13 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     // ------------------------------------------------------------------------------------------------
     // loader role
     // ------------------------------------------------------------------------------------------------
-    uint32_t aoff[8];            // halo DMA offsets of this wave's 8 pieces (pieces wq + 4 i) for the tile being loaded
+    // Halo DMA offsets of this wave's 8 pieces (pieces wq + 4 i = entries [64 (wq + 4 i), + 64) of the 4-plane image) for the tile
+    // being loaded.  Piece wq + 4 i lies in plane i >> 1 at plane entries p = 64 (wq + 4 (i & 1)) + lane: the PLANE term is the
+    // same for every lane and tile and goes into the instruction's scalar offset, so a tile costs two per-lane offsets.  (Every
+    // vector instruction of a loader wave issues ~9 cycles apart beside the partner's MFMA stream: the eight-offset version of
+    // this function and its hand-off through LDS took 1.9 k cycles per tile, tools/stamp_probe_r.py.)  The hardware's range check
+    // may see the per-lane offset only, so all four planes of every chunk must exist: Cin % 32 == 0 (the host guards).
+    uint32_t hoff[2];
     const char* img_l = nullptr;
     auto set_load_tile = [&](int mt) __attribute__((always_inline)) {
         int b, y0, x0;
@@ -300,29 +343,21 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         img_l = (const char*)a.in0 + (long long)b * a.p0 * plane_in;
         const int lane_ = lane_now();
         // Tiles whose whole 10 x 50 halo (and the row of pad entries behind it) lies inside the image need no per-entry bounds
-        // test: entry offset = ((plane H + py) W + px) 16 + delta(tile).  (Pad entries p >= 500 are never read by the compute
-        // waves: whatever in-range bytes they fetch are harmless, and an out-of-range offset reads zeros.)
+        // test.  (Pad entries p >= 500 are never read by the compute waves: whatever in-range bytes they fetch are harmless, and
+        // an out-of-range offset reads zeros.)
         const bool interior = y0 >= 1 && x0 >= 1 && y0 + TH + 2 <= a.H && x0 + TW + 1 <= a.W;
         const uint32_t delta = ((uint32_t)(y0 - 1) * (uint32_t)a.W + (uint32_t)(x0 - 1)) * 16u;
-        if (interior) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int e = 64 * (wq + 4 * i) + lane_;
-                const int plane = e >> 9, p = e & 511;
-                const int py = (p * 1311) >> 16, px = p - py * ROWW;  // p / 50 for p < 512
-                aoff[i] = (((uint32_t)plane * (uint32_t)a.H + (uint32_t)py) * (uint32_t)a.W + (uint32_t)px) * 16u + delta;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int e = 64 * (wq + 4 * i) + lane_;
-                const int plane = e >> 9, p = e & 511;
-                const int py = (p * 1311) >> 16, px = p - py * ROWW;
+        for (int j = 0; j < 2; ++j) {
+            const int p = 64 * (wq + 4 * j) + lane_;
+            const int py = (p * 1311) >> 16, px = p - py * ROWW;  // p / 50 for p < 512
+            uint32_t o = ((uint32_t)py * (uint32_t)a.W + (uint32_t)px) * 16u + delta;
+            if (!interior) {
                 const int gy = y0 - 1 + py, gx = x0 - 1 + px;
                 const bool ok = (p < NPIX) & (gy >= 0) & (gy < a.H) & (gx >= 0) & (gx < a.W);
-                aoff[i] = ok ? (((uint32_t)plane * (uint32_t)a.H + (uint32_t)py) * (uint32_t)a.W + (uint32_t)px) * 16u + delta
-                             : 0xffffffffu;  // beyond the descriptor: the hardware returns zeros
+                o = ok ? o : 0xffffffffu;  // beyond the descriptor: the hardware returns zeros
             }
+            hoff[j] = o;
         }
     };
     // LDS-DMA, one 1-KiB piece at a time (the pieces of a step are interleaved with epilogue arithmetic: an LDS-DMA instruction
@@ -331,19 +366,17 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     auto halo_piece = [&](auto i_tag, const __amdgpu_buffer_rsrc_t rsrc, char* dst) __attribute__((always_inline)) {
         constexpr int i = decltype(i_tag)::value;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + (wq + 4 * i) * 1024), 16,
-                                                 (int)aoff[i], 0, 0, 0);
+                                                 (int)hoff[i & 1], (int)((uint32_t)(i >> 1) * (uint32_t)plane_in), 0, 0);
     };
-    auto halo_rsrc = [&](int kc) __attribute__((always_inline)) {
-        const int planes = a.p0 - 4 * kc < 4 ? a.p0 - 4 * kc : 4;
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(img_l + 4LL * kc * plane_in), 0, (int)(uint32_t)(planes * plane_in), 0x00020000);
+    auto halo_rsrc = [&](int kc) __attribute__((always_inline)) {  // the four planes of chunk kc (all exist: Cin % 32 == 0)
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(img_l + 4LL * kc * plane_in), 0, (int)(uint32_t)(4 * plane_in), 0x00020000);
     };
     // weight piece j = wq + 4 i of a segment of `pieces` pieces (s0 = the segment in HBM: wave-uniform; dst = its slot)
-    auto wseg_piece = [&](auto i_tag, const char* s0, int pieces, char* dst) __attribute__((always_inline)) {
+    // (lo = 16 lane_now(), worked out ONCE per step: the piece index goes into the scalar base)
+    auto wseg_piece = [&](auto i_tag, const char* s0, int pieces, char* dst, uint32_t lo) __attribute__((always_inline)) {
         constexpr int i = decltype(i_tag)::value;
         const int j = wq + 4 * i;
-        const int lane_ = lane_now();
-        const uint32_t lo = (uint32_t)lane_ * 16u;  // scalar base + 32-bit lane offset
-        if (j < pieces) glds16(s0 + (size_t)(lo + (uint32_t)j * 1024u), dst + j * 1024);
+        if (j < pieces) glds16(s0 + (size_t)j * 1024u + lo, dst + j * 1024);
     };
     constexpr int WP = (S::pieces(0) + 3) / 4;  // weight pieces per wave and step, at most
     auto wsrc_of = [&](int nt) __attribute__((always_inline)) {
@@ -396,27 +429,46 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
             }
         }
     };
-    // entry E = 3 pf + n, worked on in four QUARTERS (accumulator register j of the pair's two fragments): v_permlane16_swap pairs
-    // the fragments' quads into the lane's 8 channels (as entry16(), mz_device.h), in place; SiLU in SCALAR f32 instructions: the
-    // same operations in the same order as silu2() (identical bits), but no packed-f32 arithmetic -- v_pk_mul_f32 / v_pk_add_f32
-    // issue 7 x slower while the SIMD's other wave streams MFMAs (tools/microbench/mb_coissue.hip: 40 cycles each against 9
-    // for v_mul_f32 and 16 for v_exp_f32 / v_rcp_f32)
-    float q_a = 0.f, q_b = 0.f;  // an entry's even quarter, kept for the pack behind its odd quarter
-    auto epi_quarter = [&](auto e_tag, auto j_tag, u32x4& o) __attribute__((always_inline)) {
-        constexpr int E = decltype(e_tag)::value, j = decltype(j_tag)::value;
+    // entry E = 3 pf + n: the activation OUT of place (accumulator elements are read where they lie), the values packed to the
+    // storage type, and only then v_permlane16_swap pairs the two fragments' quads into the lane's 8 channels (as entry16(),
+    // mz_device.h) -- on the PACKED words: two swaps per entry instead of four, on fresh registers (hipcc copied every accumulator
+    // element before swapping it in place: with the hazard s_nops a quarter of the helper's epilogue instructions, each ~9 cycles
+    // beside the partner's MFMA stream).  Identical bits: activation and rounding are per element, the swap only moves lanes.
+    // SiLU in SCALAR f32 instructions: the same operations in the same order as silu2(), but no packed-f32 arithmetic --
+    // v_pk_mul_f32 / v_pk_add_f32 issue 7 x slower while the SIMD's other wave streams MFMAs (tools/microbench/mb_coissue.hip:
+    // 40 cycles each against 9 for v_mul_f32 and 16 for v_exp_f32 / v_rcp_f32)
+    uint32_t f_xq[NF][2];  // x of the pixel fragment in work: accumulator layout, two packed pairs per channel fragment
+    u32x4 f_zb[NT];        // its z as B operands (live from part A to part D of a chunk)
+    auto entry_words = [&](auto e_tag, u32x4& o) __attribute__((always_inline)) {
+        constexpr int E = decltype(e_tag)::value;
         constexpr int pf = E / NT, n = E % NT;
-        // (no write-back into the accumulator tuples: their elements die here, so the swap and the SiLU work on them in place)
-        const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, (float)acc[pf][2 * n][j]),
-                                                         __builtin_bit_cast(uint32_t, (float)acc[pf][2 * n + 1][j]), false, false);
-        const uint32_t s0 = sw[0], s1 = sw[1];
-        float va = __builtin_bit_cast(float, s0), vb = __builtin_bit_cast(float, s1);
-        if constexpr (EPI == EPI_STORE && SILU) silu_pair(va, vb);
-        if constexpr (j & 1) {
-            o[j >> 1] = pack_pair<TT>(f32x2{q_a, va});
-            o[2 + (j >> 1)] = pack_pair<TT>(f32x2{q_b, vb});
-        } else {
-            q_a = va;
-            q_b = vb;
+        uint32_t pa[2], pb[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float a0 = acc[pf][2 * n][2 * h], a1 = acc[pf][2 * n][2 * h + 1], b0 = acc[pf][2 * n + 1][2 * h], b1 = acc[pf][2 * n + 1][2 * h + 1];
+            if constexpr (FUSE) {
+                // part D of the fused variant: the accumulators hold the gate beta; x and z of the pixel fragment in work are in
+                // f_xq / f_zb (accumulator layout, packed pairs)
+                float xa[2], za[2], xc[2], zc[2];
+                unpack2r<TT>(f_xq[2 * n][h], xa[0], xa[1]);
+                unpack2r<TT>(f_zb[n][h], za[0], za[1]);
+                unpack2r<TT>(f_xq[2 * n + 1][h], xc[0], xc[1]);
+                unpack2r<TT>(f_zb[n][2 + h], zc[0], zc[1]);
+                blend_pair_to(a0, a1, acc[pf][2 * n][2 * h], acc[pf][2 * n][2 * h + 1], xa[0], xa[1], za[0], za[1], a.inv_mix_scale);
+                blend_pair_to(b0, b1, acc[pf][2 * n + 1][2 * h], acc[pf][2 * n + 1][2 * h + 1], xc[0], xc[1], zc[0], zc[1], a.inv_mix_scale);
+            }
+            if constexpr (EPI == EPI_STORE && SILU) {
+                silu_pair_to(a0, a1, acc[pf][2 * n][2 * h], acc[pf][2 * n][2 * h + 1]);
+                silu_pair_to(b0, b1, acc[pf][2 * n + 1][2 * h], acc[pf][2 * n + 1][2 * h + 1]);
+            }
+            pa[h] = pack_pair<TT>(f32x2{a0, a1});
+            pb[h] = pack_pair<TT>(f32x2{b0, b1});
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(pa[h], pb[h], false, false);
+            o[h] = sw[0];
+            o[2 + h] = sw[1];
         }
     };
     auto epi_store = [&](auto e_tag, const u32x4& o) __attribute__((always_inline)) {
@@ -437,8 +489,6 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     //      stay in LDS for the whole launch;
     //   D: blend x + sigmoid(alpha) sigmoid(beta) (z - x) into the accumulator registers, then the three entries as usual.
     // The arithmetic is conv3s_kernel<.., FUSE>'s, operation for operation (identical bits).
-    uint32_t f_xq[NF][2];  // x of the pixel fragment in work: accumulator layout, two packed pairs per channel fragment
-    u32x4 f_zb[NT];        // its z as B operands (live from part A to part D of a chunk)
     auto fuse_a = [&](auto pf_tag) __attribute__((always_inline)) {
         constexpr int pf = decltype(pf_tag)::value;
         const bool inside = e_y + pf / 3 < a.H && e_c + 16 * (pf % 3) < a.W;
@@ -475,22 +525,9 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         gate_reads<0, 0>(wa, mix_lane);
         gate_halves<TT, 0>(acc[pf], xb, f_zb, wa, wb, mix_lane);
     };
-    auto fuse_d = [&](auto pf_tag) __attribute__((always_inline)) {
-        constexpr int pf = decltype(pf_tag)::value;
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf) {
-            float zv[4], xv[4];
-            unpack2r<TT>(f_zb[nf >> 1][(nf & 1) * 2], zv[0], zv[1]);
-            unpack2r<TT>(f_zb[nf >> 1][(nf & 1) * 2 + 1], zv[2], zv[3]);
-            unpack2r<TT>(f_xq[nf][0], xv[0], xv[1]);
-            unpack2r<TT>(f_xq[nf][1], xv[2], xv[3]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[pf][nf][j] = blend_(xv[j], zv[j], acc[pf][nf][j], a.inv_mix_scale);
-        }
-    };
     auto entry_whole = [&](auto e_tag) __attribute__((always_inline)) {
         u32x4 o;
-        epi_quarter(e_tag, ic<0>{}, o); epi_quarter(e_tag, ic<1>{}, o); epi_quarter(e_tag, ic<2>{}, o); epi_quarter(e_tag, ic<3>{}, o);
+        entry_words(e_tag, o);
         epi_store(e_tag, o);
     };
 
@@ -518,29 +555,6 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         f.w[1][1] = lds_read128<3 * 1024>(bb);
         wait_wx<0>(f.w[0][0], f.w[0][1], f.x[0][0], f.x[0][1], f.x[0][2], f.x[0][3], f.x[0][4], f.x[0][5]);
         wait_w<0>(f.w[1][0], f.w[1][1]);
-    };
-
-    // ---- halo offsets travel between the teams through LDS: the loader team works out aoff[] of the NEXT tile (tB) one step
-    //      before it requests that tile's first halo image, and leaves a copy for the other team, which becomes the loader of
-    //      tB's later chunks one tile on (it is in the compute role, without a free register, until then) ----
-    auto aoff_table = [&]() __attribute__((always_inline)) {
-        const int lane_ = lane_now();
-        return (u32x4*)(smem + S::AOFF_BASE + wq * 2048 + lane_ * 16);
-    };
-    auto aoff_publish = [&]() __attribute__((always_inline)) {
-        u32x4* t = aoff_table();
-        t[0] = u32x4{aoff[0], aoff[1], aoff[2], aoff[3]};
-        t[64] = u32x4{aoff[4], aoff[5], aoff[6], aoff[7]};
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // written before this wave reaches the step's barrier
-    };
-    auto aoff_fetch = [&](int mt) __attribute__((always_inline)) {
-        const u32x4* t = aoff_table();
-        const u32x4 lo4 = t[0], hi4 = t[64];
-        aoff[0] = lo4[0]; aoff[1] = lo4[1]; aoff[2] = lo4[2]; aoff[3] = lo4[3];
-        aoff[4] = hi4[0]; aoff[5] = hi4[1]; aoff[6] = hi4[2]; aoff[7] = hi4[3];
-        int b, y0, x0;
-        tile_origin(mt, b, y0, x0);
-        img_l = (const char*)a.in0 + (long long)b * a.p0 * plane_in;
     };
 
     // One step of the loader role while the partner team computes chunk k of tile tA.
@@ -580,10 +594,11 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
             wsrc += (size_t)(2 * S::start(qs)) * 1024;
             const int w_pieces = w_ok ? S::pieces(qs) : 0;
             char* const w_dst = smem + B_BASE + (hs >= 1 ? hs - 1 : 2) * B_SLOT;  // slot (hs + 2) % 3
-            wseg_piece(ic<0>{}, wsrc, w_pieces, w_dst); wseg_piece(ic<1>{}, wsrc, w_pieces, w_dst); wseg_piece(ic<2>{}, wsrc, w_pieces, w_dst);
-            wseg_piece(ic<3>{}, wsrc, w_pieces, w_dst); wseg_piece(ic<4>{}, wsrc, w_pieces, w_dst);
-            if constexpr (WP > 5) wseg_piece(ic<5>{}, wsrc, w_pieces, w_dst);
-            if constexpr (WP > 6) wseg_piece(ic<6>{}, wsrc, w_pieces, w_dst);
+            const uint32_t lo = (uint32_t)lane_now() * 16u;
+            wseg_piece(ic<0>{}, wsrc, w_pieces, w_dst, lo); wseg_piece(ic<1>{}, wsrc, w_pieces, w_dst, lo); wseg_piece(ic<2>{}, wsrc, w_pieces, w_dst, lo);
+            wseg_piece(ic<3>{}, wsrc, w_pieces, w_dst, lo); wseg_piece(ic<4>{}, wsrc, w_pieces, w_dst, lo);
+            if constexpr (WP > 5) wseg_piece(ic<5>{}, wsrc, w_pieces, w_dst, lo);
+            if constexpr (WP > 6) wseg_piece(ic<6>{}, wsrc, w_pieces, w_dst, lo);
             static_assert(WP <= 7, "seven weight pieces per wave and step");
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -593,9 +608,9 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         //      flight, the stores go out behind the step's last DMA piece (vmcnt: see the head of this file) ----
         if constexpr (WK == 1) {
             u32x4 o0, o1, o2;
-            if constexpr (EN > 0) { epi_quarter(ic<ES>{}, ic<0>{}, o0); epi_quarter(ic<ES>{}, ic<1>{}, o0); epi_quarter(ic<ES>{}, ic<2>{}, o0); epi_quarter(ic<ES>{}, ic<3>{}, o0); }
-            if constexpr (EN > 1) { epi_quarter(ic<ES + 1>{}, ic<0>{}, o1); epi_quarter(ic<ES + 1>{}, ic<1>{}, o1); epi_quarter(ic<ES + 1>{}, ic<2>{}, o1); epi_quarter(ic<ES + 1>{}, ic<3>{}, o1); }
-            if constexpr (EN > 2) { epi_quarter(ic<ES + 2>{}, ic<0>{}, o2); epi_quarter(ic<ES + 2>{}, ic<1>{}, o2); epi_quarter(ic<ES + 2>{}, ic<2>{}, o2); epi_quarter(ic<ES + 2>{}, ic<3>{}, o2); }
+            if constexpr (EN > 0) entry_words(ic<ES>{}, o0);
+            if constexpr (EN > 1) entry_words(ic<ES + 1>{}, o1);
+            if constexpr (EN > 2) entry_words(ic<ES + 2>{}, o2);
             if constexpr (EN > 0) epi_store(ic<ES>{}, o0);
             if constexpr (EN > 1) epi_store(ic<ES + 1>{}, o1);
             if constexpr (EN > 2) epi_store(ic<ES + 2>{}, o2);
@@ -605,10 +620,11 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         } else if constexpr (WK == 3) {
             fuse_c(ic<ES>{});
         } else if constexpr (WK == 4) {
-            // the entries' stores must be this step's ONLY vector-memory instructions behind its DMA: all blends first
-            fuse_d(ic<ES>{});
+            // (the blend is part of the entries: entry_words())
             entry_whole(ic<3 * ES>{}); entry_whole(ic<3 * ES + 1>{}); entry_whole(ic<3 * ES + 2>{});
         }
+        RS_FENCE();
+        RS_LAP(4 * rs_c + 1);
         if constexpr (sg == NSEG - 1) {
             if constexpr (last) {
                 // the epilogue is complete: clear the accumulators and prime the fragment stream for the next tile.  Unconditional
@@ -618,12 +634,11 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
             } else {
                 if (k + 2 == nchunks && okB) {  // the next step requests tB's first halo image
                     set_load_tile(b_mt);
-                    if constexpr (!FUSE) aoff_publish();
                 }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        RS_LAP(4 * rs_c + 1);
+        RS_LAP(sg == NSEG - 1 ? (last ? 26 : 25) : 4 * rs_c + 1);  // (diagnostic build: the tile hand-over work on its own counters)
         // the DMA has landed once at most this step's stores (issued behind it) are outstanding
         wait_vmcnt<VM_AFTER>();
         RS_LAP(4 * rs_c + 2);
@@ -663,9 +678,11 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         okB = b_pos < cnt;
         wB = wsrc_of(okB ? b_nt : a_nt);
         if constexpr (DO_EPI) {
-            if constexpr (FUSE) set_load_tile(a_mt);  // (no room in LDS for the offset hand-off next to the gate weights)
-            else aoff_fetch(a_mt);
+            RS_BEGIN();
+            set_load_tile(a_mt);
             epi_setup();
+            RS_FENCE();
+            RS_LAP(27);
             if constexpr (FUSE) {
                 // one pixel fragment per chunk: the tile has at least six chunks (C = 96: Cin = 192; the host guards)
                 fuse_chunk(ic<0>{}, ic<1>{}, ic<0>{}, 0);
@@ -770,7 +787,6 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         constexpr int pf = decltype(pf_tag)::value;
         fuse_a(pf_tag);
         fuse_c(pf_tag);
-        fuse_d(pf_tag);
         entry_whole(ic<3 * pf>{}); entry_whole(ic<3 * pf + 1>{}); entry_whole(ic<3 * pf + 2>{});
     };
     auto final_epilogue = [&]() __attribute__((always_inline)) {
@@ -794,14 +810,15 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
             halo_piece(ic<0>{}, r0, smem); halo_piece(ic<1>{}, r0, smem); halo_piece(ic<2>{}, r0, smem); halo_piece(ic<3>{}, r0, smem);
             halo_piece(ic<4>{}, r0, smem); halo_piece(ic<5>{}, r0, smem); halo_piece(ic<6>{}, r0, smem); halo_piece(ic<7>{}, r0, smem);
             const char* s1 = wA + (size_t)(2 * S::start(1)) * 1024;
+            const uint32_t lo = (uint32_t)lane_now() * 16u;
             char* d0 = smem + B_BASE;
             char* d1 = smem + B_BASE + B_SLOT;
-            wseg_piece(ic<0>{}, wA, S::pieces(0), d0); wseg_piece(ic<1>{}, wA, S::pieces(0), d0); wseg_piece(ic<2>{}, wA, S::pieces(0), d0);
-            wseg_piece(ic<3>{}, wA, S::pieces(0), d0); wseg_piece(ic<4>{}, wA, S::pieces(0), d0); wseg_piece(ic<5>{}, wA, S::pieces(0), d0);
-            wseg_piece(ic<6>{}, wA, S::pieces(0), d0);
-            wseg_piece(ic<0>{}, s1, S::pieces(1), d1); wseg_piece(ic<1>{}, s1, S::pieces(1), d1); wseg_piece(ic<2>{}, s1, S::pieces(1), d1);
-            wseg_piece(ic<3>{}, s1, S::pieces(1), d1); wseg_piece(ic<4>{}, s1, S::pieces(1), d1); wseg_piece(ic<5>{}, s1, S::pieces(1), d1);
-            wseg_piece(ic<6>{}, s1, S::pieces(1), d1);
+            wseg_piece(ic<0>{}, wA, S::pieces(0), d0, lo); wseg_piece(ic<1>{}, wA, S::pieces(0), d0, lo); wseg_piece(ic<2>{}, wA, S::pieces(0), d0, lo);
+            wseg_piece(ic<3>{}, wA, S::pieces(0), d0, lo); wseg_piece(ic<4>{}, wA, S::pieces(0), d0, lo); wseg_piece(ic<5>{}, wA, S::pieces(0), d0, lo);
+            wseg_piece(ic<6>{}, wA, S::pieces(0), d0, lo);
+            wseg_piece(ic<0>{}, s1, S::pieces(1), d1, lo); wseg_piece(ic<1>{}, s1, S::pieces(1), d1, lo); wseg_piece(ic<2>{}, s1, S::pieces(1), d1, lo);
+            wseg_piece(ic<3>{}, s1, S::pieces(1), d1, lo); wseg_piece(ic<4>{}, s1, S::pieces(1), d1, lo); wseg_piece(ic<5>{}, s1, S::pieces(1), d1, lo);
+            wseg_piece(ic<6>{}, s1, S::pieces(1), d1, lo);
         }
         if constexpr (FUSE) {  // the gate weights, resident for the whole launch: 36 pieces, 9 per wave
             const int lane_ = lane_now();

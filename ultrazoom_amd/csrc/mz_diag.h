@@ -23,6 +23,7 @@
         rs_t0 = rs_t1;            \
     } while (0)
 #define RS_COUNT(i) do { rs_[i] += 1; } while (0)
+#define RS_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define RS_DUMP()                                                                                              \
     do {                                                                                                       \
         unsigned long long rs_c1, rs_r1;                                                                       \
@@ -38,5 +39,6 @@
 #define RS_BEGIN() do { } while (0)
 #define RS_LAP(i) do { } while (0)
 #define RS_COUNT(i) do { } while (0)
+#define RS_FENCE() do { } while (0)
 #define RS_DUMP() do { } while (0)
 #endif

@@ -721,15 +721,16 @@ struct Runner {
             const long long pads = (long long)a.tiles_y * th * a.tiles_x * tw;
             q_common = padq <= pads;
         }
-        // conv3r_kernel: any chunk count >= 3; its stores carry 32-bit offsets inside 12 output planes / one D2S target image
-        const bool use_r = knobs.r && q_common && c.nchunks16 >= 3 &&
+        // conv3r_kernel: any chunk count >= 3 of four whole planes (its halo loads carry the plane in the scalar offset, which the
+        // hardware's range check does not cover); its stores carry 32-bit offsets inside 12 output planes / one D2S target image
+        const bool use_r = knobs.r && q_common && c.nchunks16 >= 3 && a.p0 % 4 == 0 &&
                            (epi == EPI_D2S ? (double)(c.cq_p * dtype_size(dtype) / 16) * Hout * Wout * 16.0 < 4294967296.0
                                            : 12.0 * H * W * 16.0 < 4294967296.0);
         const bool use_q = use_r || (knobs.q && q_common && c.nchunks16 % 2 == 0);
         // ... and its fused variant (conv2 + AdaptiveResidualMix, C = 96): six or more chunks (one pixel fragment's gate GEMM and
         // blend per chunk), the gate weights packed in accumulator-row order, x and out within 32-bit offsets
         bool use_rf = knobs.r && knobs.fuse16 && epi == EPI_FUSEDMIX && use_s16 && dtype != DT_F32 && c.nt == 3 && c.ntiles == 1 && c.packed16 &&
-                      mixf && mixf->packed16r && (mixf->cp0 + 31) / 32 == c.nt && persist_wgs > 0 && c.nchunks16 >= 6 &&
+                      mixf && mixf->packed16r && (mixf->cp0 + 31) / 32 == c.nt && persist_wgs > 0 && c.nchunks16 >= 6 && a.p0 % 4 == 0 &&
                       c.nchunks16 * 32 * 100 <= c.cp0 * (100 + knobs.kpad_pct) && (double)H * W * 64.0 < 4294967296.0 &&
                       12.0 * H * W * 16.0 < 4294967296.0;
         if (use_rf) {

@@ -1549,42 +1549,60 @@ __global__ __launch_bounds__(576) void mix16_kernel(const ConvArgs a) {
         load_b(ks + 12, xb0); mix16_kstep<TT, 2>(acc, f, xb1, b_addr);
         load_b(ks + 13, xb1); mix16_kstep<TT, 3>(acc, f, xb2, b_addr);
     }
-    // ---- blend and store, one pixel fragment and one channel-fragment pair at a time ----
+    // ---- blend and store, one pixel fragment and one channel-fragment pair at a time.  x and z come back in ACCUMULATOR layout
+    //      (8 bytes per lane and fragment; L2 hits: the K loop has just read these lines); the loads of group i + 1 are requested
+    //      before group i is blended -- left to itself hipcc requests them right before their use, twelve exposed L2 round trips
+    //      per tile with nothing else in flight on the CU ----
     const int nbase = ntile * 192;
     const uint32_t plane_bytes = (uint32_t)(hw * 16);
     typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
-#pragma unroll
-    for (int pf = 0; pf < 2; ++pf) {
+    struct XZ { u32x2_ x[2], z[2]; };
+    auto request = [&](int i, XZ& q) __attribute__((always_inline)) {
+        const int pf = i / 6, n = i - 6 * pf;
         const bool in = vpix[pf] != 0xffffffffu;
 #pragma unroll
-        for (int n = 0; n < 6; ++n) {
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int nf = 2 * n + k;
-                const int plane = (nbase >> 3) + 2 * nf + (g >> 1);  // channels nbase + 16 nf + 4 g ..
-                const uint32_t off = in ? vpix[pf] + (uint32_t)plane * plane_bytes + (g & 1) * 8 : 0xffffffffu;
-                const u32x2_ xq = __builtin_amdgcn_raw_buffer_load_b64(xr, (int)off, 0, 0);
-                const u32x2_ zq = __builtin_amdgcn_raw_buffer_load_b64(zr, (int)off, 0, 0);
-                float xv[4], zv[4];
-                unpack2<TT>(xq[0], xv[0], xv[1]); unpack2<TT>(xq[1], xv[2], xv[3]);
-                unpack2<TT>(zq[0], zv[0], zv[1]); unpack2<TT>(zq[1], zv[2], zv[3]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[pf][nf][j] = blend_(xv[j], zv[j], acc[pf][nf][j], a.inv_mix_scale);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float ea = acc[pf][2 * n][j], eb = acc[pf][2 * n + 1][j];
-                const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, ea), __builtin_bit_cast(uint32_t, eb),
-                                                                 false, false);
-                const uint32_t s0 = sw[0], s1 = sw[1];
-                v[j] = __builtin_bit_cast(float, s0);
-                v[4 + j] = __builtin_bit_cast(float, s1);
-            }
-            const int cu = 2 * (2 * n + (g & 1)) + (g >> 1);
-            if (in) st_unit<TT>((char*)a.out + vpix[pf] + (long long)((nbase >> 3) + cu) * plane_bytes, v);
+        for (int k = 0; k < 2; ++k) {
+            const int nf = 2 * n + k;
+            const int plane = (nbase >> 3) + 2 * nf + (g >> 1);  // channels nbase + 16 nf + 4 g ..
+            const uint32_t off = in ? vpix[pf] + (uint32_t)plane * plane_bytes + (g & 1) * 8 : 0xffffffffu;
+            q.x[k] = __builtin_amdgcn_raw_buffer_load_b64(xr, (int)off, 0, 0);
+            q.z[k] = __builtin_amdgcn_raw_buffer_load_b64(zr, (int)off, 0, 0);
         }
+    };
+    auto finish = [&](int i, const XZ& q) __attribute__((always_inline)) {
+        const int pf = i / 6, n = i - 6 * pf;
+        const bool in = vpix[pf] != 0xffffffffu;
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int nf = 2 * n + k;
+            float xv[4], zv[4];
+            unpack2<TT>(q.x[k][0], xv[0], xv[1]); unpack2<TT>(q.x[k][1], xv[2], xv[3]);
+            unpack2<TT>(q.z[k][0], zv[0], zv[1]); unpack2<TT>(q.z[k][1], zv[2], zv[3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[pf][nf][j] = blend_(xv[j], zv[j], acc[pf][nf][j], a.inv_mix_scale);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float ea = acc[pf][2 * n][j], eb = acc[pf][2 * n + 1][j];
+            const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, ea), __builtin_bit_cast(uint32_t, eb), false, false);
+            const uint32_t s0 = sw[0], s1 = sw[1];
+            v[j] = __builtin_bit_cast(float, s0);
+            v[4 + j] = __builtin_bit_cast(float, s1);
+        }
+        const int cu = 2 * (2 * n + (g & 1)) + (g >> 1);
+        if (in) st_unit<TT>((char*)a.out + vpix[pf] + (long long)((nbase >> 3) + cu) * plane_bytes, v);
+    };
+    XZ qa, qb;
+    request(0, qa);
+#pragma unroll
+    for (int i = 0; i < 12; i += 2) {
+        request(i + 1, qb);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(i, qa);
+        if (i + 2 < 12) request(i + 2, qa);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(i + 1, qb);
     }
 }
 
