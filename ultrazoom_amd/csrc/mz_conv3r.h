@@ -437,7 +437,8 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     // SiLU in SCALAR f32 instructions: the same operations in the same order as silu2(), but no packed-f32 arithmetic --
     // v_pk_mul_f32 / v_pk_add_f32 issue 7 x slower while the SIMD's other wave streams MFMAs (tools/microbench/mb_coissue.hip:
     // 40 cycles each against 9 for v_mul_f32 and 16 for v_exp_f32 / v_rcp_f32)
-    uint32_t f_xq[NF][2];  // x of the pixel fragment in work: accumulator layout, two packed pairs per channel fragment
+    uint32_t f_xq[2][NF][2];  // x of pixel fragment pf in buffer pf & 1 (requested ONE CHUNK AHEAD of its use: the loads come from HBM):
+                              // accumulator layout, two packed pairs per channel fragment
     u32x4 f_zb[NT];        // its z as B operands (live from part A to part D of a chunk)
     auto entry_words = [&](auto e_tag, u32x4& o) __attribute__((always_inline)) {
         constexpr int E = decltype(e_tag)::value;
@@ -450,9 +451,9 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
                 // part D of the fused variant: the accumulators hold the gate beta; x and z of the pixel fragment in work are in
                 // f_xq / f_zb (accumulator layout, packed pairs)
                 float xa[2], za[2], xc[2], zc[2];
-                unpack2r<TT>(f_xq[2 * n][h], xa[0], xa[1]);
+                unpack2r<TT>(f_xq[pf & 1][2 * n][h], xa[0], xa[1]);
                 unpack2r<TT>(f_zb[n][h], za[0], za[1]);
-                unpack2r<TT>(f_xq[2 * n + 1][h], xc[0], xc[1]);
+                unpack2r<TT>(f_xq[pf & 1][2 * n + 1][h], xc[0], xc[1]);
                 unpack2r<TT>(f_zb[n][2 + h], zc[0], zc[1]);
                 blend_pair_to(a0, a1, acc[pf][2 * n][2 * h], acc[pf][2 * n][2 * h + 1], xa[0], xa[1], za[0], za[1], a.inv_mix_scale);
                 blend_pair_to(b0, b1, acc[pf][2 * n + 1][2 * h], acc[pf][2 * n + 1][2 * h + 1], xc[0], xc[1], zc[0], zc[1], a.inv_mix_scale);
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     //      stay in LDS for the whole launch;
     //   D: blend x + sigmoid(alpha) sigmoid(beta) (z - x) into the accumulator registers, then the three entries as usual.
     // The arithmetic is conv3s_kernel<.., FUSE>'s, operation for operation (identical bits).
-    auto fuse_a = [&](auto pf_tag) __attribute__((always_inline)) {
+    auto fuse_x = [&](auto pf_tag) __attribute__((always_inline)) {  // request x of pixel fragment pf
         constexpr int pf = decltype(pf_tag)::value;
         const bool inside = e_y + pf / 3 < a.H && e_c + 16 * (pf % 3) < a.W;
         const long long plane_o = (long long)a.H * a.W * 16;
@@ -499,9 +500,12 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         for (int nf = 0; nf < NF; ++nf) {
             const uint32_t o = inside ? off + (uint32_t)(2 * nf) * (uint32_t)plane_o : 0xffffffffu;  // planes >= p1 fall out of range: zeros
             const auto v = __builtin_amdgcn_raw_buffer_load_b64(xrsrc, (int)o, 0, 0);
-            f_xq[nf][0] = v[0];
-            f_xq[nf][1] = v[1];
+            f_xq[pf & 1][nf][0] = v[0];
+            f_xq[pf & 1][nf][1] = v[1];
         }
+    };
+    auto fuse_z = [&](auto pf_tag) __attribute__((always_inline)) {  // z of pixel fragment pf as B operands
+        constexpr int pf = decltype(pf_tag)::value;
 #pragma unroll
         for (int m = 0; m < NT; ++m) {
             const f32x4 za = acc[pf][2 * m], zc = acc[pf][2 * m + 1];
@@ -512,13 +516,20 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
             f_zb[m] = q;
         }
     };
+    // part A of chunk pf: x of the NEXT pixel fragment (of the first two in chunk 0), z of this one
+    auto fuse_a = [&](auto pf_tag) __attribute__((always_inline)) {
+        constexpr int pf = decltype(pf_tag)::value;
+        if constexpr (pf == 0) fuse_x(ic<0>{});
+        if constexpr (pf + 1 < NPF) fuse_x(ic<(pf + 1 < NPF ? pf + 1 : 0)>{});
+        fuse_z(pf_tag);
+    };
     auto fuse_c = [&](auto pf_tag) __attribute__((always_inline)) {
         constexpr int pf = decltype(pf_tag)::value;
         const int lane_ = lane_now();
         const uint32_t mix_lane = lds_base + S::MIX_BASE + lane_ * 16;
         u32x4 xb[NT];
 #pragma unroll
-        for (int m = 0; m < NT; ++m) xb[m] = u32x4{f_xq[2 * m][0], f_xq[2 * m][1], f_xq[2 * m + 1][0], f_xq[2 * m + 1][1]};
+        for (int m = 0; m < NT; ++m) xb[m] = u32x4{f_xq[pf & 1][2 * m][0], f_xq[pf & 1][2 * m][1], f_xq[pf & 1][2 * m + 1][0], f_xq[pf & 1][2 * m + 1][1]};
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) acc[pf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
         u32x4 wa[NT], wb[NT];
@@ -570,8 +581,15 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         constexpr int rs_c = 1 + (EN > 0 ? 2 : 0) + (sg == 0 ? 0 : 1);
         static_assert(EN <= 3, "three output registers");
         // VMEM instructions this step issues BEHIND its DMA: stores of the entries, or FUSE's x loads
-        constexpr int VM_AFTER = WK == 1 ? EN : (WK == 2 ? EN * NF : (WK == 4 ? EN * NT : 0));
+        constexpr int VM_AFTER = WK == 1 ? EN : (WK == 2 ? (ES == 0 ? 2 * NF : (ES + 1 < NPF ? NF : 0)) : (WK == 4 ? EN * NT : 0));
         RS_BEGIN();
+        if constexpr (WK == 3) {
+            // x (requested in part A of the chunk before) is needed by the gate GEMM below.  hipcc cannot count the conditional DMA
+            // pieces issued in between and would wait for vmcnt(0) AFTER this step's DMA issue -- for the DMA itself, before any
+            // work.  Naming the registers here makes it wait BEFORE the DMA instead (for loads that have long landed).
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) asm volatile("" ::"v"(f_xq[ES & 1][nf][0]), "v"(f_xq[ES & 1][nf][1]));
+        }
         // ---- this step's DMA: in a chunk's first step the next chunk's halo image (first: its data comes from HBM and takes
         //      longest), then weight segment (k, sg) + 2 steps ----
         if constexpr (sg == 0) {
@@ -785,7 +803,8 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     };
     auto final_fuse_pf = [&](auto pf_tag) __attribute__((always_inline)) {
         constexpr int pf = decltype(pf_tag)::value;
-        fuse_a(pf_tag);
+        fuse_x(pf_tag);
+        fuse_z(pf_tag);
         fuse_c(pf_tag);
         entry_whole(ic<3 * pf>{}); entry_whole(ic<3 * pf + 1>{}); entry_whole(ic<3 * pf + 2>{});
     };
