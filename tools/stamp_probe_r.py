@@ -37,7 +37,7 @@ for (B, H, W, cin, cout, silu) in CASES:
         clock = f", in-kernel clock {r[28] / r[29] * 100.0:.0f} MHz over {r[28]} cycles" if r[29] > 0 else ""
         line = f"  wave {wv}: tiles {r[1]}, K loop {r[0] // n} cycles per tile, final epilogue {r[2]}{clock}"
         print(line)
-        print(f"      per tile: phase start (offsets + epilogue setup) {r[27] // n}, next tile's offsets + publish {r[25] // n}, prime (+ clear) {r[26] // n}")
+        print(f"      per tile: phase start (offsets + epilogue setup) {r[27] // n}, next tile's offsets (incl. ~350 per non-last chunk for the stamp itself) {r[25] // n}, prime (+ clear) {r[26] // n}")
         for c in (1, 2, 3, 4):
             k = max(r[20 + c], 1)
             print(f"      {NAMES[c]:30s} x{r[20 + c]:5d}: DMA issue {r[4 * c] // k:5d}  epilogue {r[4 * c + 1] // k:5d}  vmcnt wait {r[4 * c + 2] // k:5d}  barrier {r[4 * c + 3] // k:5d}")
