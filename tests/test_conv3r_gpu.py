@@ -35,7 +35,7 @@ R_CASES = [
     (3, 40, 100, 96, 192, 1, 8),   # 45 pixel tiles x 2 N tiles on 8 workgroups: ~11 tiles per workgroup, weight switches, odd counts
     (2, 13, 37, 128, 96, 1, 0),    # ragged edges in both directions, four chunks
     (1, 70, 70, 192, 96, 0, 8),    # six chunks
-    (1, 20, 130, 112, 96, 0, 8),   # Cin = 112: four chunks, the last one half zero planes
+    (1, 20, 130, 112, 96, 0, 8),   # Cin = 112: the last chunk has two planes only -> the host must NOT pick conv3r (conv3q takes it)
     (2, 9, 250, 160, 288, 1, 16),  # five chunks, three N tiles
     (1, 135, 240, 192, 96, 1, 0),  # the level-4 geometry of cfg3 (5 tiles per row, 17 tile rows)
     (1, 24, 50, 96, 80, 1, 8),     # Cout = 80: the N tile's last plane pair does not exist (range-checked stores)

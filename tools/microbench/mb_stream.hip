@@ -135,6 +135,10 @@ int main() {
     CHECK(hipFuncSetAttribute((const void*)planes_kernel<P, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     CHECK(hipFuncSetAttribute((const void*)planes_kernel<P, 6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     CHECK(hipFuncSetAttribute((const void*)planes_kernel<P, 6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    CHECK(hipFuncSetAttribute((const void*)planes_kernel<P, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    CHECK(hipFuncSetAttribute((const void*)planes_kernel<P, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    if (time_it("planes256 depth 1, one workgroup per CU (32 KB of loads in flight per CU: mix16_kernel's)", bytes, reps, [&] { hipLaunchKernelGGL((planes_kernel<P, 1, false>), dim3(B * tpi), dim3(512), 96 * 1024, 0, x, z, out, hw, tpi); })) return 1;
+    if (time_it("planes256 depth 2, one workgroup per CU", bytes, reps, [&] { hipLaunchKernelGGL((planes_kernel<P, 2, false>), dim3(B * tpi), dim3(512), 96 * 1024, 0, x, z, out, hw, tpi); })) return 1;
     if (time_it("planes256 depth 3, one workgroup per CU", bytes, reps, [&] { hipLaunchKernelGGL((planes_kernel<P, 3, false>), dim3(B * tpi), dim3(512), 96 * 1024, 0, x, z, out, hw, tpi); })) return 1;
     if (time_it("planes256 depth 6, one workgroup per CU", bytes, reps, [&] { hipLaunchKernelGGL((planes_kernel<P, 6, false>), dim3(B * tpi), dim3(512), 96 * 1024, 0, x, z, out, hw, tpi); })) return 1;
     if (time_it("planes1k depth 6, one workgroup per CU", bytes, reps, [&] { hipLaunchKernelGGL((planes_kernel<P, 6, true>), dim3(B * tpi), dim3(512), 96 * 1024, 0, x, z, out, hw, tpi); })) return 1;

@@ -23,6 +23,17 @@
 // in flight across the barrier.  For that count to be exact every store is a buffer_store whose out-of-image lanes carry
 // an out-of-range offset (dropped by the hardware's range check): the instruction is always issued.
 //
+// The helper role is the critical path of the short tiles (3 chunks: C = 96 inputs; the fused variant), and every VECTOR instruction
+// it issues costs ~9 cycles beside the partner's MFMA stream (transcendentals and v_permlane16_swap 16, packed f32 40:
+// tools/microbench/mb_coissue.hip), while scalar instructions issue at full rate.  Hence, in this file:
+//   * the activation and the fused variant's blend are inline asm of scalar-f32 instructions, two interleaved chains per block,
+//     OUT of place (accumulator elements are read where they lie; hipcc's SLP vectoriser would pair them into v_pk_* otherwise);
+//   * an epilogue entry packs to the storage type first and swaps the PACKED words between the two fragments of a pair (two
+//     v_permlane16_swap per 16-byte entry, on fresh registers: no accumulator copies, no hazard s_nops);
+//   * halo DMA offsets are two per lane and tile: the plane of a piece goes into the instruction's scalar offset (Cin % 32 == 0:
+//     the hardware's range check does not see scalar offsets, so every chunk must have its four planes; the host guards);
+//   * the lane index behind a step's weight pieces is worked out once per step, the piece index goes into the scalar base.
+//
 // NSEG = weight segments (= barriers) per 32-channel chunk: 2 (14 + 13 groups, 3 x 28 KB weight slots, as conv3q) or 3
 // (9 + 9 + 9 groups = tap rows, 3 x 18 KB slots).  NSEG = 3 leaves 42 KB of LDS free: the fused variant (EPI_FUSEDMIX)
 // keeps the 36 KB of AdaptiveResidualMix gate weights resident there for the whole launch.
@@ -55,7 +66,7 @@ template <int NSEG> struct Seg {
     static constexpr int of(int G) { return NSEG == 2 ? (G < start(1) ? 0 : 1) : G / (NG / 3); }
     static constexpr int pieces(int s) { return 2 * (start(s + 1) - start(s)); }
     static constexpr int SLOT = pieces(0) * 1024;  // the largest segment is the first
-    static constexpr int MIX_BASE = B_BASE + 3 * SLOT;   // fused variant, 36 KB: the gate weights (instead of the hand-off table)
+    static constexpr int MIX_BASE = B_BASE + 3 * SLOT;   // fused variant, 36 KB: the gate weights
     static constexpr int lds_bytes(bool fuse) { return fuse ? MIX_BASE + MIX_PIECES * 1024 : B_BASE + 3 * SLOT; }
 };
 
@@ -333,7 +344,7 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     // being loaded.  Piece wq + 4 i lies in plane i >> 1 at plane entries p = 64 (wq + 4 (i & 1)) + lane: the PLANE term is the
     // same for every lane and tile and goes into the instruction's scalar offset, so a tile costs two per-lane offsets.  (Every
     // vector instruction of a loader wave issues ~9 cycles apart beside the partner's MFMA stream: the eight-offset version of
-    // this function and its hand-off through LDS took 1.9 k cycles per tile, tools/stamp_probe_r.py.)  The hardware's range check
+    // this function and a hand-off of its results to the other team through LDS took ~1.9 k cycles per tile, tools/stamp_probe_r.py.)  The hardware's range check
     // may see the per-lane offset only, so all four planes of every chunk must exist: Cin % 32 == 0 (the host guards).
     uint32_t hoff[2];
     const char* img_l = nullptr;
