@@ -173,3 +173,40 @@ def test_conv3r_fused_mix(dt, case, monkeypatch):
     assert (got == b_).float().mean().item() > 0.98, "conv3r and conv3s fused kernels: more than 2 % of the outputs differ"
     assert ((got - b_).abs() / tol).max().item() <= 1.0, "conv3r and conv3s fused kernels differ by more than the tolerance"
     assert (pad_part(outs["r"], cout) == 0).all(), "pad channels must stay zero"
+
+
+# ---- seeded shape sweep: ragged heights / widths around the 8 x 48 tile and the 10 x 50 halo image (border and interior paths of the
+#      halo offsets, partial tiles, one-tile and many-tile workgroups), Cin of 3 .. 8 whole chunks, bf16; conv3r against conv3s bit for
+#      bit (the oracle comparison of the same kernels is in the cases above) ----
+def _sweep_cases():
+    import random
+    rng = random.Random(20261004)
+    cases = []
+    for _ in range(24):
+        H = rng.choice([8, 9, 15, 16, 17, 23, 31, 40, 57])
+        W = rng.choice([47, 48, 49, 95, 96, 97, 100, 143, 145, 191])
+        cin = 32 * rng.choice([3, 4, 5, 6, 8])
+        cout = rng.choice([96, 96, 192])
+        cases.append((rng.choice([1, 2, 3]), H, W, cin, cout, rng.choice([0, 1]), rng.choice([0, 8, 16])))
+    return cases
+
+
+@pytest.mark.parametrize("case", _sweep_cases())
+def test_conv3r_shape_sweep_equals_conv3s(case, monkeypatch):
+    dtype = DTYPES["bf16"]
+    B, H, W, cin, cout, silu, wgs = case
+    x = q(rnd((B, cin, H, W), 41), dtype)
+    w = q(wrnd((cout, cin, 3, 3), 42), dtype)
+    xa = to_act(x, dtype)
+    outs = {}
+    for name, env in {"r": {}, "s": {"MZ_NO_Q": "1", "MZ_NO_R": "1"}}.items():
+        out = alloc_act(B, cout, H, W, dtype)
+        for k in ("MZ_NO_Q", "MZ_NO_R", "MZ_PERSIST_WGS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        if wgs:
+            monkeypatch.setenv("MZ_PERSIST_WGS", str(wgs))
+        op_conv(dtype, 0, xa, None, w, 0.0, out, B, H, W, cin, cout, silu=silu)
+        outs[name] = out
+    assert torch.equal(outs["r"], outs["s"]), f"conv3r and conv3s differ on {case}"
