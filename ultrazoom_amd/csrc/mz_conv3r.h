@@ -220,27 +220,13 @@ __device__ __forceinline__ int lane_now() {
     return l;
 }
 
-// v * sigmoid(v) of TWO values, in place: v_mul, v_exp, v_add, v_rcp, v_mul each, as ONE inline-asm block with the two chains
+// v * sigmoid(v) of TWO values: v_mul, v_exp, v_add, v_rcp, v_mul each, as ONE inline-asm block with the two chains
 // interleaved.  Inline asm because hipcc's SLP vectoriser pairs the multiplies and adds into v_pk_* (7 x slower beside the
 // partner's MFMA stream); one block because hipcc's hazard recogniser does not look inside inline asm: a VALU instruction that
 // reads the result of a transcendental one needs ONE wait state, which the other chain's instruction provides (no s_nop).
 // The same operations in the same order as silu2() / sigmoidf_(): identical bits.
-__device__ __forceinline__ void silu_pair(float& a, float& b) {
-    float ta, tb;
-    asm("v_mul_f32 %2, 0xbfb8aa3b, %0\n\t"
-        "v_mul_f32 %3, 0xbfb8aa3b, %1\n\t"
-        "v_exp_f32 %2, %2\n\t"
-        "v_exp_f32 %3, %3\n\t"
-        "v_add_f32 %2, 1.0, %2\n\t"
-        "v_add_f32 %3, 1.0, %3\n\t"
-        "v_rcp_f32 %2, %2\n\t"
-        "v_rcp_f32 %3, %3\n\t"
-        "v_mul_f32 %0, %0, %2\n\t"
-        "v_mul_f32 %1, %1, %3"
-        : "+v"(a), "+v"(b), "=&v"(ta), "=&v"(tb));
-}
-// The same, OUT of place (the inputs stay untouched: accumulator elements need no copy into scratch registers first; the results
-// double as the chains' temporaries)
+// OUT of place (the inputs stay untouched: accumulator elements need no copy into scratch registers first; the results double as
+// the chains' temporaries)
 __device__ __forceinline__ void silu_pair_to(float& ra, float& rb, const float a, const float b) {
     asm("v_mul_f32 %0, 0xbfb8aa3b, %2\n\t"
         "v_mul_f32 %1, 0xbfb8aa3b, %3\n\t"
@@ -258,7 +244,7 @@ __device__ __forceinline__ void silu_pair_to(float& ra, float& rb, const float a
 
 // x + sigmoid(alpha) sigmoid(beta) (z - x) of TWO values, out of place: blend_()'s operations in blend_()'s order
 // (mz_device.h: v_mul, v_exp, v_fma, v_rcp, v_sub, v_fma; identical bits), as one inline-asm block of two interleaved chains for the
-// same reasons as silu_pair() -- left to hipcc, the SLP vectoriser pairs the adds and fmas into v_pk_add_f32 / v_pk_fma_f32.
+// same reasons as silu_pair_to() -- left to hipcc, the SLP vectoriser pairs the adds and fmas into v_pk_add_f32 / v_pk_fma_f32.
 __device__ __forceinline__ void blend_pair_to(float& o0, float& o1, const float b0, const float b1, const float x0, const float x1,
                                               const float z0, const float z1, const float inv_s) {
     float d0, d1;
@@ -382,12 +368,13 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     auto halo_rsrc = [&](int kc) __attribute__((always_inline)) {  // the four planes of chunk kc (all exist: Cin % 32 == 0)
         return __builtin_amdgcn_make_buffer_rsrc((void*)(img_l + 4LL * kc * plane_in), 0, (int)(uint32_t)(4 * plane_in), 0x00020000);
     };
-    // weight piece j = wq + 4 i of a segment of `pieces` pieces (s0 = the segment in HBM: wave-uniform; dst = its slot)
-    // (lo = 16 lane_now(), worked out ONCE per step: the piece index goes into the scalar base)
-    auto wseg_piece = [&](auto i_tag, const char* s0, int pieces, char* dst, uint32_t lo) __attribute__((always_inline)) {
+    // weight piece j = wq + 4 i of a segment of `pieces` pieces (s0 = the segment in HBM: wave-uniform; dst = its slot).
+    // lo = 16 lane_now(), worked out ONCE per step: the piece index goes into the scalar base; the wave's piece COUNT is compared with
+    // the compile-time i (per-piece indices wq + 4 i would be six more scalars for hipcc to keep alive -- and spill -- across steps)
+    auto wseg_count = [&](int pieces) __attribute__((always_inline)) { return pieces > wq ? (pieces - wq + 3) >> 2 : 0; };
+    auto wseg_piece = [&](auto i_tag, const char* s0, int mine, char* dst, uint32_t lo) __attribute__((always_inline)) {
         constexpr int i = decltype(i_tag)::value;
-        const int j = wq + 4 * i;
-        if (j < pieces) glds16(s0 + (size_t)j * 1024u + lo, dst + j * 1024);
+        if (i < mine) glds16(s0 + (size_t)wq * 1024u + (size_t)i * 4096u + lo, dst + wq * 1024 + i * 4096);
     };
     constexpr int WP = (S::pieces(0) + 3) / 4;  // weight pieces per wave and step, at most
     auto wsrc_of = [&](int nt) __attribute__((always_inline)) {
@@ -589,7 +576,7 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         constexpr int WK = decltype(wk_tag)::value;  // 1: entries [ES, ES + EN); 2 / 3 / 4: FUSE part A / C / D of EN pixel fragments from ES
         constexpr int ES = decltype(es_tag)::value, EN = WK == 0 ? 0 : decltype(en_tag)::value, sg = decltype(sg_tag)::value;
         constexpr bool last = decltype(last_tag)::value != 0;
-        constexpr int rs_c = 1 + (EN > 0 ? 2 : 0) + (sg == 0 ? 0 : 1);
+        [[maybe_unused]] constexpr int rs_c = 1 + (EN > 0 ? 2 : 0) + (sg == 0 ? 0 : 1);
         static_assert(EN <= 3, "three output registers");
         // VMEM instructions this step issues BEHIND its DMA: stores of the entries, or FUSE's x loads
         constexpr int VM_AFTER = WK == 1 ? EN : (WK == 2 ? (ES == 0 ? 2 * NF : (ES + 1 < NPF ? NF : 0)) : (WK == 4 ? EN * NT : 0));
@@ -606,7 +593,11 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         if constexpr (sg == 0) {
             if (!last || okB) {
                 const __amdgpu_buffer_rsrc_t h_rsrc = halo_rsrc(last ? 0 : k + 1);
-                char* const h_dst = smem + (us ^ 1) * A_SLOT;
+                // (opaque: hipcc would otherwise keep the eight piece addresses of a slot alive from one chunk to the next but one as
+                // spilled SGPRs -- a v_writelane / v_readlane pair each, vector instructions the helper role is short of)
+                uint32_t h_off = (uint32_t)(us ^ 1) * (uint32_t)A_SLOT;
+                asm volatile("" : "+s"(h_off));
+                char* const h_dst = smem + h_off;
                 halo_piece(ic<0>{}, h_rsrc, h_dst); halo_piece(ic<1>{}, h_rsrc, h_dst); halo_piece(ic<2>{}, h_rsrc, h_dst);
                 halo_piece(ic<3>{}, h_rsrc, h_dst); halo_piece(ic<4>{}, h_rsrc, h_dst); halo_piece(ic<5>{}, h_rsrc, h_dst);
                 halo_piece(ic<6>{}, h_rsrc, h_dst); halo_piece(ic<7>{}, h_rsrc, h_dst);
@@ -621,7 +612,7 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
             else if constexpr (!last) wsrc = wA + (size_t)(k + 1) * chunk_bytes;
             else { wsrc = wB; w_ok = okB; }
             wsrc += (size_t)(2 * S::start(qs)) * 1024;
-            const int w_pieces = w_ok ? S::pieces(qs) : 0;
+            const int w_pieces = w_ok ? wseg_count(S::pieces(qs)) : 0;
             char* const w_dst = smem + B_BASE + (hs >= 1 ? hs - 1 : 2) * B_SLOT;  // slot (hs + 2) % 3
             const uint32_t lo = (uint32_t)lane_now() * 16u;
             wseg_piece(ic<0>{}, wsrc, w_pieces, w_dst, lo); wseg_piece(ic<1>{}, wsrc, w_pieces, w_dst, lo); wseg_piece(ic<2>{}, wsrc, w_pieces, w_dst, lo);
@@ -843,12 +834,12 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
             const uint32_t lo = (uint32_t)lane_now() * 16u;
             char* d0 = smem + B_BASE;
             char* d1 = smem + B_BASE + B_SLOT;
-            wseg_piece(ic<0>{}, wA, S::pieces(0), d0, lo); wseg_piece(ic<1>{}, wA, S::pieces(0), d0, lo); wseg_piece(ic<2>{}, wA, S::pieces(0), d0, lo);
-            wseg_piece(ic<3>{}, wA, S::pieces(0), d0, lo); wseg_piece(ic<4>{}, wA, S::pieces(0), d0, lo); wseg_piece(ic<5>{}, wA, S::pieces(0), d0, lo);
-            wseg_piece(ic<6>{}, wA, S::pieces(0), d0, lo);
-            wseg_piece(ic<0>{}, s1, S::pieces(1), d1, lo); wseg_piece(ic<1>{}, s1, S::pieces(1), d1, lo); wseg_piece(ic<2>{}, s1, S::pieces(1), d1, lo);
-            wseg_piece(ic<3>{}, s1, S::pieces(1), d1, lo); wseg_piece(ic<4>{}, s1, S::pieces(1), d1, lo); wseg_piece(ic<5>{}, s1, S::pieces(1), d1, lo);
-            wseg_piece(ic<6>{}, s1, S::pieces(1), d1, lo);
+            wseg_piece(ic<0>{}, wA, wseg_count(S::pieces(0)), d0, lo); wseg_piece(ic<1>{}, wA, wseg_count(S::pieces(0)), d0, lo); wseg_piece(ic<2>{}, wA, wseg_count(S::pieces(0)), d0, lo);
+            wseg_piece(ic<3>{}, wA, wseg_count(S::pieces(0)), d0, lo); wseg_piece(ic<4>{}, wA, wseg_count(S::pieces(0)), d0, lo); wseg_piece(ic<5>{}, wA, wseg_count(S::pieces(0)), d0, lo);
+            wseg_piece(ic<6>{}, wA, wseg_count(S::pieces(0)), d0, lo);
+            wseg_piece(ic<0>{}, s1, wseg_count(S::pieces(1)), d1, lo); wseg_piece(ic<1>{}, s1, wseg_count(S::pieces(1)), d1, lo); wseg_piece(ic<2>{}, s1, wseg_count(S::pieces(1)), d1, lo);
+            wseg_piece(ic<3>{}, s1, wseg_count(S::pieces(1)), d1, lo); wseg_piece(ic<4>{}, s1, wseg_count(S::pieces(1)), d1, lo); wseg_piece(ic<5>{}, s1, wseg_count(S::pieces(1)), d1, lo);
+            wseg_piece(ic<6>{}, s1, wseg_count(S::pieces(1)), d1, lo);
         }
         if constexpr (FUSE) {  // the gate weights, resident for the whole launch: 36 pieces, 9 per wave
             const int lane_ = lane_now();
