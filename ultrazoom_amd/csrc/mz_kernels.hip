@@ -150,8 +150,9 @@ __device__ __forceinline__ bool map_tile(const ConvArgs& a, int& mtile, int& nti
 
 // PixelShuffle(2) + bicubic skip + residual add (+ clamp) -> NCHW image (reference model.py:926-930, 156, 162, 177).
 // U8: both images are uint8 (a compile-time switch: a per-load branch would serialise the 48 taps of every lane).
+constexpr int kFinalWinBytes = 15 * 64 * 4;  // per wave: the bicubic window of a 32-pixel fragment (5 rows x 3 channels x 64 columns x 4 bytes)
 template <class TT, int NT, bool U8>
-__device__ __forceinline__ void final_epilogue(const ConvArgs& a, f32x16 (&acc)[2][NT], char* ep, int lane, int b,
+__device__ __forceinline__ void final_epilogue(const ConvArgs& a, f32x16 (&acc)[2][NT], char* ep, char* win, int lane, int b,
                                                const int (&ey)[2], const int (&ex)[2]) {
     constexpr int SZ = TT::SZ;
     const int h = lane >> 5, r = lane & 31;
@@ -179,59 +180,76 @@ __device__ __forceinline__ void final_epilogue(const ConvArgs& a, f32x16 (&acc)[
         for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
             for (int c = 0; c < 3; ++c) zres[i2][c] = *(const float*)(ep + px * ROWF + ((2 * i2 + jj) * 4 + c) * 4);
-        if (y < a.H && x < a.W) {
-            // horizontal taps of this output column
+        if (y < a.H) {  // (wave-uniform)
+            // The bicubic skip reads a 4 x 4 window of the input image per output pixel.  The 64 output columns x 2 output rows of this
+            // fragment share ONE window of 4 (R = 4, 8: both rows fall into the same phase half of a source pixel) or 5 (R = 2) image
+            // rows x at most 37 columns x 3 channels: the wave loads it once, lane l taking column cbase + l of every row and channel
+            // (12 or 15 two-byte loads per lane), passes it through LDS, and every lane picks its 16 taps per channel from there.
+            // Before, every lane loaded its own 96 taps: the kernel was bound by the number of load INSTRUCTIONS (a 64-lane load of
+            // any width occupies the CU's address unit for 16 cycles; 95 % of the image head's time).
             const int R = a.R;
-            const int kx = X / R, phx = X - kx * R;
-            const float sx = (phx + 0.5f) / (float)R - 0.5f;
-            const int fx = sx < 0.0f ? -1 : 0;
-            float cx[4];
-            cubic_coeffs(sx - (float)fx, cx);
-            int colx[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) colx[i] = min(max(kx + fx - 1 + i, 0), a.Wi - 1);
+            int row0[2];
+            float cy[2][4];
 #pragma unroll
             for (int i2 = 0; i2 < 2; ++i2) {
                 const int Y = 2 * y + i2;
                 const int ky = Y / R, phy = Y - ky * R;
                 const float sy = (phy + 0.5f) / (float)R - 0.5f;
                 const int fy = sy < 0.0f ? -1 : 0;
-                float cy[4];
-                cubic_coeffs(sy - (float)fy, cy);
-                int rowy[4];
+                cubic_coeffs(sy - (float)fy, cy[i2]);
+                row0[i2] = ky + fy - 1;  // first (unclamped) row of the 4-tap window
+            }
+            const int rbase = __builtin_amdgcn_readfirstlane(row0[0] < row0[1] ? row0[0] : row0[1]);
+            const int d0 = __builtin_amdgcn_readfirstlane(row0[0] - rbase), d1 = __builtin_amdgcn_readfirstlane(row0[1] - rbase);  // 0 or 1
+            const bool five = (d0 | d1) != 0;
+            const int cbase = __builtin_amdgcn_readfirstlane((2 * ex[mf]) / R) - 2;  // column of window slot 0 (fx - 1 >= -2)
+            const int wcol = min(max(cbase + lane, 0), a.Wi - 1);                    // (slots past the window hold clamped repeats)
+            uint32_t* const wl = (uint32_t*)win;
+            uint32_t wv[15];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) rowy[i] = min(max(ky + fy - 1 + i, 0), a.Hi - 1);
-                // all 48 taps of this output row first (one opaque statement per channel pins "every load issued before
-                // any use": left alone, hipcc serialises them as load -> wait -> multiply), then the arithmetic
-                uint32_t raw[3][16];
+            for (int c = 0; c < 3; ++c) {
+                const long long ip = ((long long)b * 3 + c) * plane_i;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const long long ip = ((long long)b * 3 + c) * plane_i;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const long long rp = ip + (long long)rowy[i] * a.Wi;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) raw[c][4 * i + k] = ld_img_raw<TT, U8>(a.img, rp + colx[k]);
-                    }
+                for (int i = 0; i < 5; ++i) {
+                    if (i == 4 && !five) { wv[c * 5 + i] = 0u; break; }
+                    wv[c * 5 + i] = ld_img_raw<TT, U8>(a.img, ip + (long long)min(max(rbase + i, 0), a.Hi - 1) * a.Wi + wcol);
                 }
+            }
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    asm volatile("" : "+v"(raw[c][0]), "+v"(raw[c][1]), "+v"(raw[c][2]), "+v"(raw[c][3]), "+v"(raw[c][4]),
-                                      "+v"(raw[c][5]), "+v"(raw[c][6]), "+v"(raw[c][7]), "+v"(raw[c][8]), "+v"(raw[c][9]),
-                                      "+v"(raw[c][10]), "+v"(raw[c][11]), "+v"(raw[c][12]), "+v"(raw[c][13]),
-                                      "+v"(raw[c][14]), "+v"(raw[c][15]));
+            for (int j = 0; j < 15; ++j) wl[j * 64 + lane] = wv[j];
+            __builtin_amdgcn_wave_barrier();
+            if (x < a.W) {
+                // horizontal taps of this output column
+                const int kx = X / R, phx = X - kx * R;
+                const float sx = (phx + 0.5f) / (float)R - 0.5f;
+                const int fx = sx < 0.0f ? -1 : 0;
+                float cx[4];
+                cubic_coeffs(sx - (float)fx, cx);
+                // window slot of the first tap: slot s holds column clamp(cbase + s), so slots o .. o + 3 are exactly the clamped taps
+                // clamp(kx + fx - 1 + k) of the per-lane version; 0 <= o, o + 3 <= 36 (R = 2)
+                const int o = kx + fx - 1 - cbase;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    float sres = 0.0f;
+                    // the rows' horizontal sums once, shared by both output rows (same operations in the same order as a per-row loop)
+                    float rowv[5];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float rowv = img_cvt<TT, U8>(raw[c][4 * i]) * cx[0] + img_cvt<TT, U8>(raw[c][4 * i + 1]) * cx[1] +
-                                           img_cvt<TT, U8>(raw[c][4 * i + 2]) * cx[2] + img_cvt<TT, U8>(raw[c][4 * i + 3]) * cx[3];
-                        sres += rowv * cy[i];
+                    for (int i = 0; i < 5; ++i) {
+                        if (i == 4 && !five) { rowv[i] = 0.f; break; }
+                        const uint32_t* t = wl + (c * 5 + i) * 64 + o;
+                        rowv[i] = img_cvt<TT, U8>(t[0]) * cx[0] + img_cvt<TT, U8>(t[1]) * cx[1] + img_cvt<TT, U8>(t[2]) * cx[2] +
+                                  img_cvt<TT, U8>(t[3]) * cx[3];
                     }
-                    float v = sres + zres[i2][c];
-                    if (a.clamp) v = fminf(fmaxf(v, 0.0f), 1.0f);
-                    st_img<TT, U8>(a.out, (((long long)b * 3 + c) * plane_o) + (long long)Y * a.Wout + X, v);
+#pragma unroll
+                    for (int i2 = 0; i2 < 2; ++i2) {
+                        const int d = i2 == 0 ? d0 : d1;
+                        float sres = 0.0f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sres += (d ? rowv[i + 1] : rowv[i]) * cy[i2][i];
+                        float v = sres + zres[i2][c];
+                        if (a.clamp) v = fminf(fmaxf(v, 0.0f), 1.0f);
+                        const int Y = 2 * y + i2;
+                        st_img<TT, U8>(a.out, (((long long)b * 3 + c) * plane_o) + (long long)Y * a.Wout + X, v);
+                    }
                 }
             }
         }
@@ -336,12 +354,12 @@ __device__ __forceinline__ void store_epilogue(const ConvArgs& a, f32x16 (&acc)[
 // ================================================================================================
 template <class TT, int NT, bool IS_CONV>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const int epi, const int silu, f32x16 (&acc)[2][NT], char* ep,
-                                              int lane, int nbase, int b, const int (&ey)[2], const int (&ex)[2],
+                                              char* win, int lane, int nbase, int b, const int (&ey)[2], const int (&ex)[2],
                                               const long long (&em)[2]) {
     if (epi == EPI_FINAL) {
         if (IS_CONV) {
-            if (a.io_u8) final_epilogue<TT, NT, true>(a, acc, ep, lane, b, ey, ex);
-            else final_epilogue<TT, NT, false>(a, acc, ep, lane, b, ey, ex);
+            if (a.io_u8) final_epilogue<TT, NT, true>(a, acc, ep, win, lane, b, ey, ex);
+            else final_epilogue<TT, NT, false>(a, acc, ep, win, lane, b, ey, ex);
         }
         return;
     }
@@ -700,9 +718,9 @@ __global__ __launch_bounds__(576, 3) void conv3w_kernel(const ConvArgs a) {
                     for (int j = 0; j < 4; ++j) acc[mf][nt][4 * q + j] = v[j];
                 }
         __builtin_amdgcn_s_barrier();  // every wave is done with the gate weights: the ring can take epilogue data
-        conv_epilogue<TT, NT, true>(a, EPI_STORE, 0, acc, smem + w * EPW, lane, nbase, b, ey, ex, em);
+        conv_epilogue<TT, NT, true>(a, EPI_STORE, 0, acc, smem + w * EPW, smem + 8 * EPW + w * kFinalWinBytes, lane, nbase, b, ey, ex, em);
     } else {
-        conv_epilogue<TT, NT, true>(a, a.epi, a.silu, acc, smem + w * EPW, lane, nbase, b, ey, ex, em);
+        conv_epilogue<TT, NT, true>(a, a.epi, a.silu, acc, smem + w * EPW, smem + 8 * EPW + w * kFinalWinBytes, lane, nbase, b, ey, ex, em);
     }
 }
 
@@ -1786,7 +1804,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvArgs a) {
         const int ey[2] = {y0 + 2 * w, y0 + 2 * w + 1};
         const int ex[2] = {x0, x0};
         const long long em[2] = {m0 + 64 * w, m0 + 64 * w + 32};
-        conv_epilogue<TT, NT, MODE == MODE_CONV3>(a, a.epi, a.silu, acc, smem + w * EPW, lane, nbase, b, ey, ex, em);
+        conv_epilogue<TT, NT, MODE == MODE_CONV3>(a, a.epi, a.silu, acc, smem + w * EPW, smem + 4 * EPW + w * kFinalWinBytes, lane, nbase, b, ey, ex, em);
     }
 }
 
