@@ -5,18 +5,23 @@ cap; nothing failed when that happened.  This test compi
 (device code only, no GPU needed) with -Rpass-analysis=kernel-resource-usage and fails if a persistent 3x3 kernel, the mix
 kernel or the image head reports ScratchSize != 0 or VGPR spills."""
 
+import os
 import re
 import shutil
 import subprocess
+import sys
+import tempfile
 from pathlib import Path
 
 import pytest
 
 CSRC = Path(__file__).resolve().parent.parent / "ultrazoom_amd" / "csrc"
+TOOLS = Path(__file__).resolve().parent.parent / "tools"
+LISTINGS = {}
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 # kernels the execution plans of the 16-bit modes use (name prefix of the demangled-ish symbol)
-HOT = ("conv3r_kernel", "conv3q_kernel", "conv3s_kernel", "mix16_kernel", "conv3w_kernel")
+HOT = ("conv3r_kernel", "conv3q_kernel", "conv3s_kernel", "mix16_kernel", "mix16b_kernel", "conv3w_kernel")
 # Instantiations that are NOT on the default plans of the 16-bit modes and are known to spill (fallbacks / A-B knobs):
 #   conv3s_kernel<T, NT = 3, *, FUSE>: the C = 65..96 fused conv2 + mix; conv3r_kernel's fused variant takes it wherever the tile has six
 #                                      or more chunks (hidden_ratio >= 2), so this one only runs for hidden_ratio 1 or MZ_NO_R=1
@@ -25,9 +30,12 @@ EXEMPT = (re.compile(r"conv3s_kernelINS_\w+ELi3ELi\dELb1E"), re.compile(r"conv3w
 
 
 def resource_usage(src: str):
-    p = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-c", "-Rpass-analysis=kernel-resource-usage",
-                        str(CSRC / src), "-o", "/dev/null"], capture_output=True, text=True, timeout=1500)
+    """One device-only compile per translation unit: the resource remarks on stderr, the assembly listing kept for the hazard scan."""
+    asm = Path(tempfile.gettempdir()) / f"mz_guard_{os.getpid()}_{src}.s"
+    p = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-Rpass-analysis=kernel-resource-usage",
+                        str(CSRC / src), "-o", str(asm)], capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stderr[-2000:]
+    LISTINGS[src] = asm
     out = {}
     name = None
     for line in p.stderr.splitlines():
@@ -57,3 +65,15 @@ def test_hot_kernels_use_no_scratch():
         for k, v in hot.items():
             if "conv3r_kernel" in k or "conv3q_kernel" in k:
                 assert v.get("Occupancy", v.get("Occupancy [waves/SIMD]", 2)) >= 2, f"{k}: two waves per SIMD are the design"
+    # The same listings, scanned for the store-data hazard hipcc does not know on gfx950: a 16-byte buffer store with an SGPR offset
+    # whose data registers are overwritten within two wait states (mix16b_kernel wrote garbage in a third of its runs before its
+    # stores were followed by a pinned `s_nop 1`; tools/asm_store_hazard.py).
+    sys.path.insert(0, str(TOOLS))
+    import asm_store_hazard
+
+    try:
+        hazards = {src: asm_store_hazard.scan(str(path)) for src, path in LISTINGS.items()}
+    finally:
+        for path in LISTINGS.values():
+            path.unlink(missing_ok=True)
+    assert not any(hazards.values()), f"store-data hazards in the listings: {hazards}"

@@ -180,6 +180,37 @@ def test_adaptive_residual_mix(dt, case):
         assert pad_part(out, c).abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("wgs", ["", "8"])
+@pytest.mark.parametrize("case", [(1, 9, 40), (2, 33, 65), (3, 16, 16)])
+def test_mix_c192_both_kernels(dt, case, wgs, monkeypatch):
+    """C = 192 runs mix16b_kernel (persistent; gate rows in B-operand order: x, z and beta of a 16-byte entry in one lane, x and z
+    read once); MZ_NO_MIX16B=1 keeps mix16_kernel (blend in accumulator layout).  Both against the oracle (model.py:826-839), and
+    against each other: same K order inside every MFMA, same blend arithmetic => identical bits.  MZ_PERSIST_WGS=8: 64 waves, so
+    that every wave walks several 32-pixel units (the loop that loads the next unit between the stores of the current one)."""
+    dtype = DTYPES[dt]
+    B, H, W = case
+    if wgs:
+        monkeypatch.setenv("MZ_PERSIST_WGS", wgs)
+    c = 192
+    x = q(rnd((B, c, H, W), 27), dtype)
+    z = q(rnd((B, c, H, W), 28), dtype)
+    w = q(wrnd((c, 2 * c, 1, 1), 29), dtype)
+    alpha = -0.21
+    want = oracle.residual_mix(x, z, w, torch.tensor(alpha))
+    outs = {}
+    for knob in ("0", "1"):
+        if knob == "1":
+            monkeypatch.setenv("MZ_NO_MIX16B", "1")
+        else:
+            monkeypatch.delenv("MZ_NO_MIX16B", raising=False)
+        out = alloc_act(B, c, H, W, dtype)
+        op_conv(dtype, 3, to_act(x, dtype), to_act(z, dtype), w, alpha, out, B, H, W, 2 * c, c)
+        outs[knob] = from_act(out, c)
+        assert_op_close(outs[knob], want, dt)
+    assert torch.equal(outs["0"], outs["1"])
+
+
 @pytest.mark.parametrize("dt", list(DTYPES))
 @pytest.mark.parametrize("case", [(2, 9, 11, 16), (1, 33, 40, 48), (1, 8, 8, 24)])
 def test_stem(dt, case):

@@ -111,7 +111,12 @@ __device__ __forceinline__ void group_mfmas(f32x4 (&acc)[NPF][NF], Frag& f, cons
         constexpr int T = GC + 2;      // group whose weights are requested now
         constexpr bool t_here = T < Ge;
         constexpr int t_idx = t_here ? T - Gs : T - Ge;  // its index inside its segment
-        constexpr int k = M / 6, pf = M % 6;
+        // Order of a group's 12 MFMAs: pixel-fragment major, the channel pair in serpentine order, and the odd pair of a tap walks the
+        // pixel fragments backwards -- from one MFMA to the next exactly ONE operand changes, and the B operand (pixels) only every
+        // second time (18 -> 16 changes per tap instead of 36).  Same FLOPs, same registers, same sums (every accumulator still sees
+        // its MFMAs in K order), but the chip is power-limited in this loop and holds a higher clock: deep layers -2 %, whole forward
+        // -1 % against the channel-major raster order (tools/microbench/mb_order.hip).
+        constexpr int pf = (n & 1) ? 5 - M / 2 : M / 2, k = ((M / 2) & 1) ? 1 - (M & 1) : (M & 1);
         if constexpr (ZERO_C) {  // a tile's first tap WRITES the accumulators (C = 0): nobody has to clear 144 registers per tile
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
             if constexpr (TT::IS_BF16)

@@ -65,6 +65,7 @@ struct Knobs {
     bool s16 = true;        // MZ_NO_S16=1: keep 16-bit types on the 32x32x16 kernels
     bool fuse16 = true;     // MZ_NO_FUSE16=1: the fused mix stays on the 32x32x16 kernel
     bool mix16 = true;      // MZ_NO_MIX16=1: C = k * 192 mixes on the general 1x1 kernel
+    bool mix16b = true;     // MZ_NO_MIX16B=1: ... on mix16_kernel (blend in accumulator layout, x and z read twice) instead of mix16b_kernel
     int persist = -1;       // MZ_NO_PERSIST=1 -> 0 (one workgroup per tile); MZ_PERSIST_WGS=n -> n; -1 = one per CU
     int kpad_pct = 12;      // MZ_KPAD_PCT=n: the 16x16x32 kernels take Cin whose padding to whole 32-channel chunks is <= n %
     int blk4 = 1;           // MZ_NO_BLK4=1: row-major tile walk inside an image (A/B of the L2 sharing of vertical halos)
@@ -79,6 +80,7 @@ static Knobs read_knobs() {
     k.s16 = getenv("MZ_NO_S16") == nullptr;
     k.fuse16 = getenv("MZ_NO_FUSE16") == nullptr;
     k.mix16 = getenv("MZ_NO_MIX16") == nullptr;
+    k.mix16b = getenv("MZ_NO_MIX16B") == nullptr;
     k.q = getenv("MZ_NO_Q") == nullptr;
     k.r = getenv("MZ_NO_R") == nullptr;
     k.blk4 = getenv("MZ_NO_BLK4") == nullptr;
@@ -414,6 +416,11 @@ static int pack_conv(ConvW& c, int dtype, const float* w_dev, hipStream_t s) {
         p.dst = c.packed16; p.frag16 = 1; p.nchunks = c.nchunks16;
         if (c.in_map == SRC_CONCAT) { p.nt = 6; p.ntiles = c.cout / 192; }  // mix16_kernel: 12 fragments per K step
         HIPCHK(launch_pack(p, s));
+        if (c.in_map == SRC_CONCAT && c.nchunks16 == 12) {  // C = 192, mix16b_kernel: rows in B-operand order, own channels first
+            if (!c.packed16r) HIPCHK(hipMalloc(&c.packed16r, c.packed16_sz));
+            p.dst = c.packed16r; p.frag16 = 3;
+            HIPCHK(launch_pack(p, s));
+        }
         if (c.in_map == SRC_MIXF && c.nt == 3) {
             if (!c.packed16r) HIPCHK(hipMalloc(&c.packed16r, c.packed16_sz));
             p.dst = c.packed16r; p.frag16 = 2;
@@ -823,16 +830,23 @@ struct Runner {
         a.inv_mix_scale = 1.0f + std::exp(-alpha);
         const bool mix16 = c.packed16 != nullptr && knobs.mix16 &&
                            (double)npix * c.cp0 * sz < 4294967296.0;  // 32-bit buffer offsets inside each tensor
-        if (mix16) {  // 192-channel N tiles, x / z straight into MFMA operands (mix16_kernel)
+        int mix16b_wgs = knobs.persist > 0 ? knobs.persist : 0;  // persistent (also under MZ_NO_PERSIST=1: it has no per-tile form)
+        if (mix16b_wgs == 0) {
+            int dev = 0;
+            if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDevices) mix16b_wgs = g_dev_cus[dev];
+        }
+        const bool mix16b = mix16 && knobs.mix16b && c.packed16r != nullptr && c.nchunks16 == 12 && mix16b_wgs > 0;  // C = 192
+        if (mix16) {  // 192-channel N tiles, x / z straight into MFMA operands (mix16_kernel / mix16b_kernel)
             a.ntiles = c.cout / 192;
-            a.wpk16 = c.packed16;
+            a.wpk16 = mix16b ? c.packed16r : c.packed16;
             a.nchunks16 = c.nchunks16;
         }
         pick_order(a, c, (double)npix * (c.cp0 + pad16(c.c1)) * sz, mix16 ? 32 : 64);
         ProfRec* r;
         prof_begin(r, 2.0 * (double)npix * c.cin * c.cout, (double)npix * 3.0 * c.cout * sz, 0);
         if (r) { r->kind = 1; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.gm * 1000 + a.gn; }
-        if (mix16) check(launch_mix16(dtype, a, s), "mix16 launch");
+        if (mix16b) check(launch_mix16b(dtype, a, s, mix16b_wgs), "mix16b launch");
+        else if (mix16) check(launch_mix16(dtype, a, s), "mix16 launch");
         else check(launch_conv(dtype, MODE_GEMM1, c.nt, a, s), "mix launch");
         prof_end(r);
     }

@@ -87,6 +87,9 @@ int gemm1_chunks_per_stage();
 hipError_t launch_conv(int dtype, int mode, int nt, const ConvArgs& a, hipStream_t s);
 // AdaptiveResidualMix for C = k * 192 on the 16x16x32 MFMA (16-bit types): a.wpk16 / a.nchunks16 = K steps over [x ; z]
 hipError_t launch_mix16(int dtype, const ConvArgs& a, hipStream_t s);
+// C = 192 without the second read of x and z: a.wpk16 = gate weights packed with PackArgs::frag16 = 3 (accumulator rows in B-operand
+// order); the gate matrix stays in LDS, every wave walks its own 32-pixel units
+hipError_t launch_mix16b(int dtype, const ConvArgs& a, hipStream_t s, int workgroups);  // persistent: at most `workgroups` (one per CU)
 hipError_t init_kernels();  // raises the dynamic-LDS limits (per device)
 // conv3q_kernel (mz_conv3q.hip): 3x3 convolution, 16-bit types, 96-channel N tiles (NT = 3), 8 x 48 pixel tiles, one
 // 512-register wave per SIMD.  a.persist workgroups of 256 threads; a.wpk16 / a.nchunks16 as for conv3s_kernel.
@@ -112,6 +115,7 @@ struct PackArgs {
     int in_map;        // SrcKind
     int frag16;        // 1: fragments of the 16x16x32 MFMA (16 channels x 32 K; 16-bit types); nchunks counts 32-channel chunks.  2 (SRC_MIXF): ... with
                        // the x half of the gate weights in accumulator-row order as well (conv3r_kernel's fused variant)
+                       // 3 (SRC_CONCAT, nt = 6): mix16b_kernel's row and K-step order
     int c0, cp0, c1;   // CONCAT: real/padded channels of in0, real channels of in1;  PLAIN/CRUSH: c0 = cin, cp0 = padded cin
 };
 size_t packed_bytes(int taps, int nt, int ntiles, int nchunks);

@@ -969,7 +969,9 @@ __device__ __forceinline__ void s16_mfmas(f32x4 (&acc)[4][2 * NT], Frag16& f, ui
     if constexpr (M < 8) {
         using P = S16Plan<NT, G, GE>;
         constexpr int t = P::t, n = P::n, xp = t & 1, wp = G % 3;
-        constexpr int k = M >> 2, pf = M & 3;
+        // pixel-fragment major, the channel pair in serpentine order, odd pairs of a tap walk the pixel fragments backwards: one operand
+        // changes per MFMA (conv3r_kernel's order, DESIGN.md 5.2c: the same sums at a higher clock)
+        constexpr int pf = (n & 1) ? 3 - (M >> 1) : (M >> 1), k = ((M >> 1) & 1) ? 1 - (M & 1) : (M & 1);
         mma16<TT>(acc[pf][2 * n + k], f.w[wp][k], f.x[xp][pf]);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (P::w_issue && M < 2) {
@@ -1450,10 +1452,11 @@ __device__ __forceinline__ void mix16_group(f32x4 (&acc)[2][12], MixFrag& f, con
         f.w[(G + 2) % 3][1] = lds_read128<(((G + 2) / 6) * 12 + 2 * ((G + 2) % 6) + 1) * 1024>(b_addr);
     }
     __builtin_amdgcn_sched_barrier(0);
-    mma16<TT>(acc[0][2 * n], f.w[wp][0], xb[0]);
-    mma16<TT>(acc[1][2 * n], f.w[wp][0], xb[1]);
-    mma16<TT>(acc[0][2 * n + 1], f.w[wp][1], xb[0]);
-    mma16<TT>(acc[1][2 * n + 1], f.w[wp][1], xb[1]);
+    constexpr int p0 = G & 1, p1 = p0 ^ 1;   // serpentine: one operand changes per MFMA; odd groups start on the other pixel fragment,
+    mma16<TT>(acc[p0][2 * n], f.w[wp][0], xb[p0]);           // so the B operand also stays put across a group boundary
+    mma16<TT>(acc[p0][2 * n + 1], f.w[wp][1], xb[p0]);
+    mma16<TT>(acc[p1][2 * n + 1], f.w[wp][1], xb[p1]);
+    mma16<TT>(acc[p1][2 * n], f.w[wp][0], xb[p1]);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (G + 1 < 24) wait_w16<(G + 2 < 24 ? 2 : 0)>(f.w[(G + 1) % 3][0], f.w[(G + 1) % 3][1]);
 }
@@ -1631,6 +1634,174 @@ hipError_t launch_mix16(int dtype, const ConvArgs& a, hipStream_t s) {
     switch (dtype) {
         case DT_BF16: hipLaunchKernelGGL(mix16_kernel<TBF16>, dim3(a.grid), dim3(576), lds, s, a); break;
         case DT_F16: hipLaunchKernelGGL(mix16_kernel<TF16>, dim3(a.grid), dim3(576), lds, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ================================================================================================
+// mix16b_kernel (round 3, second session): AdaptiveResidualMix for C = 192 without the second read of x and z, persistent.
+// mix16_kernel blends in accumulator layout and therefore fetches x and z a second time (8-byte loads, L2 hit rate 0.38 at
+// C = 192: counted traffic 2.79 GB against 1.79 GB algorithmic -- DESIGN 5.3), and its workgroup -- the only one its CU has room
+// for -- alternates between a read-only K loop and a write-only epilogue.  Here
+//   * the gate weights are packed (PackArgs::frag16 = 3) so that accumulator row 4 g + j of channel fragment 2 m + h is channel
+//     32 m + 8 g + 4 h + j: lane (g, c) then owns, as accumulators, exactly the eight channels of pixel c that it loaded as the B
+//     operand of K step m -- x, z and beta of one 16-byte plane entry sit in ONE lane: the 24 B operands of a unit (96 registers)
+//     are kept until the blend, no second read, no v_permlane16_swap, one 16-byte store per entry;
+//   * the whole gate matrix (144 KB) stays in LDS for the life of the workgroup (one per CU, eight waves of 256 registers, no loader
+//     wave): after the first barrier there is no barrier and no LDS-DMA at all; every WAVE walks its own 32-pixel units;
+//   * the loads of a wave's NEXT unit are issued between the stores of the current one, entry by entry into the registers the blend
+//     has just released: reads and writes of a CU overlap, and the next K loop finds its first operands on the way.
+// C = 192 only (one N tile whose twelve K steps are all its own): for C > 192 the other K steps have to stream through rotating
+// buffers next to the 96 kept registers and hipcc spills in that loop, so C = 384 / 768 stay on mix16_kernel.
+// ================================================================================================
+template <class TT>
+__global__ __launch_bounds__(512) void mix16b_kernel(const ConvArgs a) {
+    constexpr int STAGE = 4 * 12 * 1024;  // 4 K steps x 12 fragments
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7
+    {   // the gate matrix: 144 pieces of 1 KB, 18 per wave
+        const char* wsrc = (const char*)a.wpk16 + lane * 16 + w * (18 * 1024);
+        char* dst = smem + w * (18 * 1024);
+#pragma unroll
+        for (int j = 0; j < 18; ++j) glds16(wsrc + j * 1024, dst + j * 1024);
+    }
+    const int g = lane >> 4, c = lane & 15;
+    const long long hw = (long long)a.Ho * a.Wo;
+    const long long M = (long long)a.B * hw;
+    const uint32_t tensor_bytes = (uint32_t)((long long)a.B * a.p0 * hw * 16);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.in0, 0, (int)tensor_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc((void*)a.in1, 0, (int)tensor_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)tensor_bytes, 0x00020000);
+    const uint32_t step_bytes = (uint32_t)(4 * hw * 16);  // four planes per K step
+    const float inv_hw = 1.0f / (float)hw;
+    // (image, plane g, pixel) -> bytes for the lane's pixel of fragment pf of unit u; 0xffffffff beyond the tensor: the range check
+    // returns zeros for such loads and drops such stores
+    const int hwi = (int)hw, Mi = (int)M;   // the host guarantees B * p0 * hw * 16 < 2^32, so B * hw < 2^24
+    auto offsets = [&](int u, uint32_t (&vo)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pf = 0; pf < 2; ++pf) {
+            const int m = u * 32 + 16 * pf + c;
+            const bool in = m < Mi;
+            const int mm = in ? m : 0;
+            int bimg = (int)((float)mm * inv_hw);  // estimate (exact float of mm < 2^24), then corrected: no integer division per unit
+            int pix = mm - bimg * hwi;
+            if (pix < 0) { bimg -= 1; pix += hwi; }
+            if (pix >= hwi) { bimg += 1; pix -= hwi; }
+            vo[pf] = in ? ((uint32_t)(bimg * a.p0 + g) * (uint32_t)hwi + (uint32_t)pix) * 16u : 0xffffffffu;
+        }
+    };
+    const int nunits = (Mi + 31) / 32;
+    const int stride = (int)gridDim.x * 8;
+    int u = (int)blockIdx.x * 8 + w;
+    uint32_t voff[2];
+    offsets(u, voff);
+    u32x4 R[12][2];  // x K steps 0..5, z K steps 0..5 of the current unit
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int so = __builtin_amdgcn_readfirstlane((int)(i * step_bytes));
+#pragma unroll
+        for (int pf = 0; pf < 2; ++pf) R[i][pf] = __builtin_amdgcn_raw_buffer_load_b128(xr, (int)voff[pf], so, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int so = __builtin_amdgcn_readfirstlane((int)(i * step_bytes));
+#pragma unroll
+        for (int pf = 0; pf < 2; ++pf) R[6 + i][pf] = __builtin_amdgcn_raw_buffer_load_b128(zr, (int)voff[pf], so, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    wait_vmcnt<0>();                // this wave's 18 pieces of the gate matrix (once per workgroup: the first unit's loads may as well land)
+    __builtin_amdgcn_s_barrier();   // the only barrier of the kernel: every wave reaches it, also one without a unit
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t b_lane = lds_base + lane * 16;
+    MixFrag f;
+    auto stage_head = [&](uint32_t b_addr) __attribute__((always_inline)) {
+        f.w[0][0] = lds_read128<0>(b_addr);
+        f.w[0][1] = lds_read128<1024>(b_addr);
+        f.w[1][0] = lds_read128<2048>(b_addr);
+        f.w[1][1] = lds_read128<3072>(b_addr);
+        wait_w16<2>(f.w[0][0], f.w[0][1]);
+    };
+    while (u < nunits) {
+        // the next unit's offsets first: here the accumulators are dead and their registers hold the temporaries
+        const int un = u + stride;
+        uint32_t vnext[2];
+        offsets(un, vnext);   // beyond the last unit: 0xffffffff, the loads return zeros and nobody uses them
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[2][12];
+#pragma unroll
+        for (int pf = 0; pf < 2; ++pf)
+#pragma unroll
+            for (int nf = 0; nf < 12; ++nf) acc[pf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        stage_head(b_lane);
+        mix16_kstep<TT, 0>(acc, f, R[0], b_lane);
+        mix16_kstep<TT, 1>(acc, f, R[1], b_lane);
+        mix16_kstep<TT, 2>(acc, f, R[2], b_lane);
+        mix16_kstep<TT, 3>(acc, f, R[3], b_lane);
+        stage_head(b_lane + STAGE);
+        mix16_kstep<TT, 0>(acc, f, R[4], b_lane + STAGE);
+        mix16_kstep<TT, 1>(acc, f, R[5], b_lane + STAGE);
+        mix16_kstep<TT, 2>(acc, f, R[6], b_lane + STAGE);
+        mix16_kstep<TT, 3>(acc, f, R[7], b_lane + STAGE);
+        stage_head(b_lane + 2 * STAGE);
+        mix16_kstep<TT, 0>(acc, f, R[8], b_lane + 2 * STAGE);
+        mix16_kstep<TT, 1>(acc, f, R[9], b_lane + 2 * STAGE);
+        mix16_kstep<TT, 2>(acc, f, R[10], b_lane + 2 * STAGE);
+        mix16_kstep<TT, 3>(acc, f, R[11], b_lane + 2 * STAGE);
+        // ---- blend and store entry (K step m, pixel fragment pf) = plane 4 m + g of the lane's pixel; behind it, the same entry's
+        //      x and z of the wave's next unit go into the registers just released ----
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+            const int so = __builtin_amdgcn_readfirstlane((int)(m * step_bytes));
+#pragma unroll
+            for (int pf = 0; pf < 2; ++pf) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float xl, xh, zl, zh;
+                    unpack2<TT>(R[m][pf][q], xl, xh);
+                    unpack2<TT>(R[6 + m][pf][q], zl, zh);
+                    v[2 * q] = blend_(xl, zl, acc[pf][2 * m + (q >> 1)][2 * (q & 1)], a.inv_mix_scale);
+                    v[2 * q + 1] = blend_(xh, zh, acc[pf][2 * m + (q >> 1)][2 * (q & 1) + 1], a.inv_mix_scale);
+                }
+                u32x4 t;
+                if constexpr (TT::IS_BF16) {
+                    t[0] = pack_bf16(v[0], v[1]); t[1] = pack_bf16(v[2], v[3]); t[2] = pack_bf16(v[4], v[5]); t[3] = pack_bf16(v[6], v[7]);
+                } else {
+                    t[0] = pack_f16(v[0], v[1]); t[1] = pack_f16(v[2], v[3]); t[2] = pack_f16(v[4], v[5]); t[3] = pack_f16(v[6], v[7]);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(t, orr, (int)voff[pf], so, 0);
+                // A 16-byte buffer store with an SGPR offset reads its data registers up to two cycles after issue on this chip, and
+                // hipcc's hazard recogniser only knows the rule for stores WITHOUT a register offset: it put the next entry's first
+                // v_mul into v[data + 2] right behind the store, and the entry of K step 1 left with garbage in its upper half in a
+                // third of the runs (tools/debug/mix192_probe.py).  Two wait states, pinned.
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 1");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int pf = 0; pf < 2; ++pf) {
+                R[m][pf] = __builtin_amdgcn_raw_buffer_load_b128(xr, (int)vnext[pf], so, 0);
+                R[6 + m][pf] = __builtin_amdgcn_raw_buffer_load_b128(zr, (int)vnext[pf], so, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        u = un;
+        voff[0] = vnext[0];
+        voff[1] = vnext[1];
+    }
+}
+
+hipError_t launch_mix16b(int dtype, const ConvArgs& a, hipStream_t s, int workgroups) {
+    if (a.mtiles <= 0 || a.ntiles != 1 || workgroups <= 0) return hipErrorInvalidValue;
+    if (a.nchunks16 != 12) return hipErrorInvalidValue;  // C = 192: twelve K steps over [x ; z], all of them the N tile's own
+    const size_t lds = 3 * 4 * 12 * 1024;  // the whole gate matrix
+    const int grid = a.mtiles < workgroups ? a.mtiles : workgroups;   // a.mtiles = 256-pixel tiles = 8 units each
+    switch (dtype) {
+        case DT_BF16: hipLaunchKernelGGL(mix16b_kernel<TBF16>, dim3(grid), dim3(512), lds, s, a); break;
+        case DT_F16: hipLaunchKernelGGL(mix16b_kernel<TF16>, dim3(grid), dim3(512), lds, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1942,6 +2113,8 @@ hipError_t init_kernels() {
     hipError_t e;
     if ((e = hipFuncSetAttribute((const void*)mix16_kernel<TBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 12 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)mix16_kernel<TF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 12 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)mix16b_kernel<TBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 4 * 12 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)mix16b_kernel<TF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 4 * 12 * 1024)) != hipSuccess) return e;
     if ((e = set_lds_all<TF32>()) != hipSuccess) return e;
     if ((e = set_lds_all<TBF16>()) != hipSuccess) return e;
     if ((e = set_lds_all<TF16>()) != hipSuccess) return e;
@@ -1965,7 +2138,14 @@ template <class TT> __global__ void pack_kernel(const PackArgs a, long long tota
     const int tap = (int)(t % a.taps); t /= a.taps;
     const int kc = (int)(t % a.nchunks); t /= a.nchunks;
     const int nb = (int)t;
-    const int n = a.frag16 ? (nb * nfr + nt) * 16 + (lane & 15) : (nb * a.nt + nt) * 32 + (lane & 31);
+    int n = a.frag16 ? (nb * nfr + nt) * 16 + (lane & 15) : (nb * a.nt + nt) * 32 + (lane & 31);
+    if (a.frag16 == 3) {
+        // mix16b_kernel: accumulator rows in B-OPERAND order.  Row r = 4 g + j of fragment 2 m + h stands for channel
+        // 32 m + 8 g + 4 h + j of the N tile, so that lane (g, c) of the accumulators owns exactly the eight channels whose x and z it
+        // loaded as the B operand of K step m: the blend needs no second read of x and z, and its result is a whole 16-byte entry
+        const int r = lane & 15;
+        n = nb * (nfr * 16) + 32 * (nt >> 1) + 8 * (r >> 2) + 4 * (nt & 1) + (r & 3);
+    }
     const int hh = lane >> 5;
     const int kin = a.frag16 ? (lane >> 4) * 8 + e : hh * (CK / 2) + e;  // channel within the chunk
     const int ckk = a.frag16 ? 32 : CK;                                  // channels per chunk
@@ -1989,7 +2169,20 @@ template <class TT> __global__ void pack_kernel(const PackArgs a, long long tota
         ty = tap / a.kw;
         tx = tap - ty * a.kw;
     } else if (a.in_map == SRC_CONCAT) {
-        const int k = kc * ckk + kin;
+        int ks = kc;
+        if (a.frag16 == 3) {
+            // ... and the K steps of an N tile start with its OWN x and z channels (six steps each, kept in registers for the blend);
+            // the rest follows in natural order (mix16b_step() in the kernel is the same map)
+            const int hs = a.nchunks >> 1, t6 = 6 * nb;
+            if (kc < 6) ks = t6 + kc;
+            else if (kc < 12) ks = hs + t6 + (kc - 6);
+            else {
+                ks = kc - 12;
+                if (ks >= t6) ks += 6;
+                if (ks >= hs + t6) ks += 6;
+            }
+        }
+        const int k = ks * ckk + kin;
         if (k < a.cp0) ci = k < a.c0 ? k : -1;
         else ci = (k - a.cp0) < a.c1 ? a.c0 + (k - a.cp0) : -1;
     } else if (a.in_map == SRC_MIXF && a.frag16) {
