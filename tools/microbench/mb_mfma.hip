@@ -72,6 +72,29 @@ __global__ __launch_bounds__(512) void mfma_loop(const u32x4* __restrict__ opera
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) total += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    } else if constexpr (SHAPE == 18) {
+        // the 16x16x32 bf16 loop again, walked the way the shipped kernels walk a group since round 3: groups of two A fragments,
+        // B-major, the A pair in serpentine order, odd groups backwards -- ONE operand changes per MFMA (tools/microbench/mb_order.hip:
+        // +3 % over the raster order above at identical FLOPs, registers and instruction count; the chip is power-limited here)
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int m = 0; m < 16; ++m) {
+                    const int grp = m >> 3, jj = (m & 7) >> 1, j = grp ? 3 - jj : jj, i = 2 * grp + ((jj & 1) ? 1 - (m & 1) : (m & 1));
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) total += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
     } else {
         f32x16 acc[2][2];  // the same 64 x 64 wave tile as 2 x 2 fragments of 32 x 32
 #pragma unroll
@@ -190,6 +213,8 @@ int main(int argc, char** argv) {
     Result r16x1, r16x2, r32x1, r32x2;
     if (run<16>(256, cus, ops, sink, clocks, iters, min_seconds, r16x1)) return 1;
     if (run<16>(512, cus, ops, sink, clocks, iters, min_seconds, r16x2)) return 1;
+    Result s16x1;
+    if (run<18>(256, cus, ops, sink, clocks, iters, min_seconds, s16x1)) return 1;
     if (run<32>(256, cus, ops, sink, clocks, iters, min_seconds, r32x1)) return 1;
     if (run<32>(512, cus, ops, sink, clocks, iters, min_seconds, r32x2)) return 1;
     // the fp16 shape of the same loop, on random fp16 operands (does the chip clock the two 16-bit types alike?)
@@ -199,17 +224,18 @@ int main(int argc, char** argv) {
     Result h16x1, h16x2;
     if (run<17>(256, cus, ops, sink, clocks, iters, min_seconds, h16x1)) return 1;
     if (run<17>(512, cus, ops, sink, clocks, iters, min_seconds, h16x2)) return 1;
-    const double best = std::max(std::max(r16x1.tflops, r16x2.tflops), std::max(r32x1.tflops, r32x2.tflops));
+    const double best = std::max(std::max(std::max(r16x1.tflops, r16x2.tflops), std::max(r32x1.tflops, r32x2.tflops)), s16x1.tflops);
     printf("{\"device\": \"%s\", \"cus\": %d, \"operands\": \"uniform random bf16 in [-1,1), register resident\", "
            "\"min_seconds_per_variant\": %.1f, \"measured_peak_tflops\": %.1f, \"variants\": {"
            "\"16x16x32_1wave_per_simd\": {\"tflops\": %.1f, \"clock_mhz\": %.0f, \"seconds\": %.2f}, "
            "\"16x16x32_2waves_per_simd\": {\"tflops\": %.1f, \"clock_mhz\": %.0f, \"seconds\": %.2f}, "
+           "\"16x16x32_serpentine_1wave_per_simd\": {\"tflops\": %.1f, \"clock_mhz\": %.0f, \"seconds\": %.2f}, "
            "\"32x32x16_1wave_per_simd\": {\"tflops\": %.1f, \"clock_mhz\": %.0f, \"seconds\": %.2f}, "
            "\"32x32x16_2waves_per_simd\": {\"tflops\": %.1f, \"clock_mhz\": %.0f, \"seconds\": %.2f}, "
            "\"f16_16x16x32_1wave_per_simd\": {\"tflops\": %.1f, \"clock_mhz\": %.0f, \"seconds\": %.2f}, "
            "\"f16_16x16x32_2waves_per_simd\": {\"tflops\": %.1f, \"clock_mhz\": %.0f, \"seconds\": %.2f}}}\n",
            prop.name, cus, min_seconds, best, r16x1.tflops, r16x1.clock_mhz, r16x1.seconds, r16x2.tflops, r16x2.clock_mhz,
-           r16x2.seconds, r32x1.tflops, r32x1.clock_mhz, r32x1.seconds, r32x2.tflops, r32x2.clock_mhz, r32x2.seconds, h16x1.tflops,
+           r16x2.seconds, s16x1.tflops, s16x1.clock_mhz, s16x1.seconds, r32x1.tflops, r32x1.clock_mhz, r32x1.seconds, r32x2.tflops, r32x2.clock_mhz, r32x2.seconds, h16x1.tflops,
            h16x1.clock_mhz, h16x1.seconds, h16x2.tflops, h16x2.clock_mhz, h16x2.seconds);
     return 0;
 }
