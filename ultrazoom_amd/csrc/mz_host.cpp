@@ -1051,12 +1051,13 @@ extern "C" int mz_op_conv(int dtype, int kind, const void* in0, const void* in1,
         case 3: plan_conv(c, dtype, MODE_GEMM1, cout, 2 * cout, 1, 1, OUT_PLAIN, SRC_CONCAT, cout, cout); break;
         default: return fail(MZ_ERR_INVALID_ARGUMENT, "bad op kind %d", kind);
     }
-    TempBuf zero, packed, packed16;
+    TempBuf zero, packed, packed16, packed16r;
     HIPCHK(hipMalloc(&zero.p, 4096));
     HIPCHK(hipMemsetAsync(zero.p, 0, 4096, s));
     rc = pack_conv(c, dtype, w_dev_f32, s);
     packed.p = c.packed;
     packed16.p = c.packed16;
+    packed16r.p = c.packed16r;   // kind 3, C = 192: the second packing of the gate weights (mix16b_kernel)
     if (rc) return rc;
     // a throw-away handle carries the zero page / staging choice for Runner
     mz_handle fake;
