@@ -77,3 +77,23 @@ def test_hot_kernels_use_no_scratch():
         for path in LISTINGS.values():
             path.unlink(missing_ok=True)
     assert not any(hazards.values()), f"store-data hazards in the listings: {hazards}"
+
+
+def test_store_hazard_scanner_on_synthetic_listings(tmp_path):
+    """The scanner itself: the instruction pair hipcc produced in mix16b_kernel is flagged, the pinned `s_nop 1` clears it, an
+    immediate offset (hipcc covers that case itself) and a write to other registers are not flagged."""
+    sys.path.insert(0, str(TOOLS))
+    import asm_store_hazard
+
+    def count(body: str) -> int:
+        f = tmp_path / "k.s"
+        f.write_text("_Z6kernelv:\n" + body)
+        return asm_store_hazard.scan(str(f))
+
+    store = "\tbuffer_store_dwordx4 v[48:51], v183, s[16:19], s2 offen\n"
+    assert count(store + "\tv_mul_f32_e32 v50, 0xbfb8aa3b, v166\n") == 1
+    assert count(store + "\ts_mov_b32 s4, 0\n\tv_mul_f32_e32 v50, 0xbfb8aa3b, v166\n") == 1       # one wait state is not enough
+    assert count(store + "\ts_nop 1\n\tv_mul_f32_e32 v50, 0xbfb8aa3b, v166\n") == 0
+    assert count(store + "\tv_mul_f32_e32 v52, 0xbfb8aa3b, v166\n\tv_exp_f32_e32 v53, v52\n") == 0
+    assert count("\tbuffer_store_dwordx4 v[48:51], v183, s[16:19], 0 offen\n\tv_mul_f32_e32 v50, 0xbfb8aa3b, v166\n") == 0
+    assert count(store + "\tbuffer_load_dwordx4 v[48:51], v185, s[8:11], s2 offen\n") == 1
