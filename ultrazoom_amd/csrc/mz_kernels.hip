@@ -1440,6 +1440,29 @@ __global__ __launch_bounds__(640) void conv3s_kernel(const ConvArgs a) {
 // Workgroup = 256 pixels x 192 channels: wave w owns pixels 32 w .. 32 w + 31 (two 16-pixel fragments) x 12 channel
 // fragments = 96 accumulator registers; weight pairs are read two 4-MFMA groups ahead with counted lgkmcnt.
 // ================================================================================================
+// blend_() of TWO values as one inline-asm block of two interleaved scalar-f32 chains (blend_()'s operations in blend_()'s order: identical
+// bits).  Left to hipcc, the SLP vectoriser pairs the subtractions and fmas of neighbouring values into v_pk_add_f32 / v_pk_fma_f32, and
+// packed-f32 instructions take ~40 cycles beside the MFMA stream of the SIMD's other wave instead of ~9 (tools/microbench/mb_coissue.hip,
+// DESIGN.md 5.0) -- in mix16b_kernel a wave's blend runs beside its partner's K loop most of the time.
+__device__ __forceinline__ void mix_blend_pair(float& o0, float& o1, const float b0, const float b1, const float x0, const float x1,
+                                               const float z0, const float z1, const float inv_s) {
+    float d0, d1;
+    asm("v_mul_f32 %0, 0xbfb8aa3b, %4\n\t"
+        "v_mul_f32 %1, 0xbfb8aa3b, %5\n\t"
+        "v_exp_f32 %0, %0\n\t"
+        "v_exp_f32 %1, %1\n\t"
+        "v_fma_f32 %0, %0, %10, %10\n\t"
+        "v_fma_f32 %1, %1, %10, %10\n\t"
+        "v_rcp_f32 %0, %0\n\t"
+        "v_rcp_f32 %1, %1\n\t"
+        "v_sub_f32 %2, %8, %6\n\t"
+        "v_sub_f32 %3, %9, %7\n\t"
+        "v_fma_f32 %0, %0, %2, %6\n\t"
+        "v_fma_f32 %1, %1, %3, %7"
+        : "=&v"(o0), "=&v"(o1), "=&v"(d0), "=&v"(d1)
+        : "v"(b0), "v"(b1), "v"(x0), "v"(x1), "v"(z0), "v"(z1), "s"(inv_s));
+}
+
 struct MixFrag {
     u32x4 w[3][2];
 };
@@ -1600,8 +1623,10 @@ __global__ __launch_bounds__(576) void mix16_kernel(const ConvArgs a) {
             float xv[4], zv[4];
             unpack2<TT>(q.x[k][0], xv[0], xv[1]); unpack2<TT>(q.x[k][1], xv[2], xv[3]);
             unpack2<TT>(q.z[k][0], zv[0], zv[1]); unpack2<TT>(q.z[k][1], zv[2], zv[3]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[pf][nf][j] = blend_(xv[j], zv[j], acc[pf][nf][j], a.inv_mix_scale);
+            float o0, o1, o2, o3;
+            mix_blend_pair(o0, o1, acc[pf][nf][0], acc[pf][nf][1], xv[0], xv[1], zv[0], zv[1], a.inv_mix_scale);
+            mix_blend_pair(o2, o3, acc[pf][nf][2], acc[pf][nf][3], xv[2], xv[3], zv[2], zv[3], a.inv_mix_scale);
+            acc[pf][nf] = f32x4{o0, o1, o2, o3};
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1763,8 +1788,8 @@ __global__ __launch_bounds__(512) void mix16b_kernel(const ConvArgs a) {
                     float xl, xh, zl, zh;
                     unpack2<TT>(R[m][pf][q], xl, xh);
                     unpack2<TT>(R[6 + m][pf][q], zl, zh);
-                    v[2 * q] = blend_(xl, zl, acc[pf][2 * m + (q >> 1)][2 * (q & 1)], a.inv_mix_scale);
-                    v[2 * q + 1] = blend_(xh, zh, acc[pf][2 * m + (q >> 1)][2 * (q & 1) + 1], a.inv_mix_scale);
+                    mix_blend_pair(v[2 * q], v[2 * q + 1], acc[pf][2 * m + (q >> 1)][2 * (q & 1)], acc[pf][2 * m + (q >> 1)][2 * (q & 1) + 1], xl, xh, zl, zh,
+                                   a.inv_mix_scale);
                 }
                 u32x4 t;
                 if constexpr (TT::IS_BF16) {
