@@ -31,8 +31,8 @@ typedef struct mz_handle mz_handle;
 
 typedef enum mz_dtype {
     MZ_F32 = 0,  /* exact f32 MFMA (v_mfma_f32_32x32x2_f32): the 1e-3 max-abs verification mode */
-    MZ_BF16 = 1, /* bf16 storage + v_mfma_f32_32x32x16_bf16, f32 accumulate and f32 epilogues  */
-    MZ_F16 = 2   /* fp16 storage + v_mfma_f32_32x32x16_f16,  f32 accumulate and f32 epilogues  */
+    MZ_BF16 = 1, /* bf16 storage, v_mfma_f32_16x16x32_bf16 (3x3 convolutions, mixes) / 32x32x16 (image head, 1x1), f32 accumulate and epilogues */
+    MZ_F16 = 2   /* fp16 storage, v_mfma_f32_16x16x32_f16 / 32x32x16, f32 accumulate and epilogues */
 } mz_dtype;
 
 typedef enum mz_status {
@@ -97,7 +97,7 @@ int mz_workspace_bytes(const mz_handle* h, int B, int H, int W, int max_images_i
 
 /* x        [B,3,H,W]      input, handle dtype
  * out_sr   [B,3,rH,rW]    s + head(unet(stem(x))) (model.py:162); clamped to [0,1] when clamp != 0
- *                         (model.py:177), NULL to skip nothing — must be non-NULL
+ *                         (model.py:177); must not be NULL
  * out_qa   [B,F] float32  degradation features z_qa (model.py:159,1026-1032), or NULL to skip the
  *                         quality head (upscale() discards it, model.py:175)
  */
@@ -165,6 +165,15 @@ int mz_profile_read(mz_handle* h, double* conv_ms, double* conv_flops, double* c
  * when the process was started with MZ_DEBUG_STAMPS=1 and is written only by -DMZ_STAMP builds of the kernels
  * (tools/stamp_probe*.py); returns -1 when it does not exist.  No reference counterpart. */
 int mz_debug_read(unsigned long long* host_dst);
+
+/* Hardware probe (ultrazoom_amd/csrc/mz_probe.hip; tests/test_store_hazard_gpu.py): on every CU, 16-byte buffer stores each followed --
+ * `wait_states` (0, 1, 2) wait states later -- by a vector instruction that overwrites data register `dword` (0..3) of the store:
+ * follower 0 v_mov_b32, 1 v_mul_f32, 2 v_cvt_pk_bf16_f32, 3 v_exp_f32, 4 v_pk_mul_f32, 5 v_mfma_f32_16x16x32_bf16;
+ * form 0 = buffer_store_dwordx4 with soffset 0, 1 = ... with soffset in an SGPR, 2 = global_store_dwordx4 with a 64-bit vaddr, 3 = ... with
+ * saddr.  `iters` (a multiple of 8) stores per wave,
+ * `blocks` workgroups of four waves.  counts_out[0] = 16-byte entries that reached memory with anything but the register contents at
+ * issue, counts_out[1..4] = per dword.  Returns 0, negative on bad arguments / HIP errors.  No reference counterpart. */
+int mz_debug_store_hazard(int follower, int form, int wait_states, int dword, int iters, int blocks, unsigned int* counts_out);
 
 #ifdef __cplusplus
 }

@@ -65,9 +65,9 @@ def test_hot_kernels_use_no_scratch():
         for k, v in hot.items():
             if "conv3r_kernel" in k or "conv3q_kernel" in k:
                 assert v.get("Occupancy", v.get("Occupancy [waves/SIMD]", 2)) >= 2, f"{k}: two waves per SIMD are the design"
-    # The same listings, scanned for the store-data hazard hipcc does not know on gfx950: a 16-byte buffer store with an SGPR offset
-    # whose data registers are overwritten within two wait states (mix16b_kernel wrote garbage in a third of its runs before its
-    # stores were followed by a pinned `s_nop 1`; tools/asm_store_hazard.py).
+    # The same listings, scanned for the store-data hazard of gfx950: a 12- / 16-byte store (buffer or global, any offset form) whose data
+    # registers are overwritten within two wait states -- hipcc inserts none behind a buffer store with an SGPR offset and one behind the
+    # other forms, and tests/test_store_hazard_gpu.py measured corruption at that distance (tools/asm_store_hazard.py follows branches).
     sys.path.insert(0, str(TOOLS))
     import asm_store_hazard
 
@@ -80,20 +80,46 @@ def test_hot_kernels_use_no_scratch():
 
 
 def test_store_hazard_scanner_on_synthetic_listings(tmp_path):
-    """The scanner itself: the instruction pair hipcc produced in mix16b_kernel is flagged, the pinned `s_nop 1` clears it, an
-    immediate offset (hipcc covers that case itself) and a write to other registers are not flagged."""
+    """The scanner itself.  The pair hipcc produced in mix16b_kernel is flagged and the pinned `s_nop 1` clears it; every 16-byte store
+    form is held to two wait states (profiles/r04_store_hazard_probe.json: the buffer store with soffset 0 still corrupts with the ONE
+    wait state hipcc inserts); writers include loads, packed and matrix instructions and both operands of a lane swap; a store at the end
+    of a loop body is checked against the loop head; writes to other registers, stores and scalar code are not flagged."""
     sys.path.insert(0, str(TOOLS))
     import asm_store_hazard
 
     def count(body: str) -> int:
         f = tmp_path / "k.s"
-        f.write_text("_Z6kernelv:\n" + body)
+        f.write_text("_Z6kernelv:                             ; @_Z6kernelv\n" + body)
         return asm_store_hazard.scan(str(f))
 
     store = "\tbuffer_store_dwordx4 v[48:51], v183, s[16:19], s2 offen\n"
-    assert count(store + "\tv_mul_f32_e32 v50, 0xbfb8aa3b, v166\n") == 1
-    assert count(store + "\ts_mov_b32 s4, 0\n\tv_mul_f32_e32 v50, 0xbfb8aa3b, v166\n") == 1       # one wait state is not enough
-    assert count(store + "\ts_nop 1\n\tv_mul_f32_e32 v50, 0xbfb8aa3b, v166\n") == 0
+    mul50 = "\tv_mul_f32_e32 v50, 0xbfb8aa3b, v166\n"
+    assert count(store + mul50) == 1
+    assert count(store + "\ts_mov_b32 s4, 0\n" + mul50) == 1       # one wait state is not enough
+    assert count(store + "\ts_nop 0\n" + mul50) == 1
+    assert count(store + "\ts_nop 1\n" + mul50) == 0
+    assert count(store + "\ts_mov_b32 s4, 0\n\ts_mov_b32 s5, 0\n" + mul50) == 0
     assert count(store + "\tv_mul_f32_e32 v52, 0xbfb8aa3b, v166\n\tv_exp_f32_e32 v53, v52\n") == 0
-    assert count("\tbuffer_store_dwordx4 v[48:51], v183, s[16:19], 0 offen\n\tv_mul_f32_e32 v50, 0xbfb8aa3b, v166\n") == 0
     assert count(store + "\tbuffer_load_dwordx4 v[48:51], v185, s[8:11], s2 offen\n") == 1
+    assert count(store + "\tbuffer_store_dwordx4 v[48:51], v184, s[16:19], s2 offen\n" + "\ts_nop 1\n" + mul50) == 0   # stores read, they do not write
+    # the other store forms: soffset 0 / an immediate, global stores with and without saddr, 12-byte stores
+    for st in ("\tbuffer_store_dwordx4 v[48:51], v183, s[16:19], 0 offen\n", "\tbuffer_store_dwordx4 v[48:51], v183, s[16:19], 0 offen offset:64\n",
+               "\tglobal_store_dwordx4 v[190:191], v[48:51], off\n", "\tglobal_store_dwordx4 v7, v[48:51], s[4:5]\n",
+               "\tglobal_store_dwordx3 v[190:191], v[48:50], off offset:16\n"):
+        assert count(st + mul50) == 1, st
+        assert count(st + "\ts_nop 0\n" + mul50) == 1, st      # what hipcc inserts for these forms: not enough on gfx950
+        assert count(st + "\ts_nop 1\n" + mul50) == 0, st
+    # 8-byte stores read their data at issue: not this hazard
+    assert count("\tglobal_store_dwordx2 v[190:191], v[50:51], off\n" + mul50) == 0
+    # writers: packed f32 (a register pair), MFMA (the accumulator tuple), lane swaps (both operands)
+    assert count(store + "\tv_pk_mul_f32 v[50:51], v[4:5], v[6:7]\n") == 1
+    assert count(store + "\tv_pk_mul_f32 v[52:53], v[48:49], v[50:51]\n") == 0          # reads them only
+    assert count(store + "\tv_mfma_f32_16x16x32_bf16 v[48:51], v[4:7], v[8:11], v[48:51]\n") == 1
+    assert count(store + "\tv_mfma_f32_16x16x32_bf16 a[48:51], v[4:7], v[8:11], a[48:51]\n") == 0   # AGPRs are another file
+    assert count(store + "\tv_permlane16_swap_b32_e32 v7, v49\n") == 1
+    # a store at the end of a loop body against the head of the loop (and the fall-through path)
+    loop = ".LBB0_1:\n" + mul50 + "\tv_add_f32_e32 v1, v2, v3\n\tv_add_f32_e32 v1, v2, v3\n" + store
+    assert count(loop + "\ts_cbranch_scc1 .LBB0_1\n\ts_endpgm\n") == 1
+    assert count(loop + "\ts_nop 0\n\ts_cbranch_scc1 .LBB0_1\n\ts_endpgm\n") == 0   # nop + branch: two wait states
+    assert count(loop + "\ts_cbranch_scc1 .LBB0_1\n" + mul50) == 1                      # ... the fall-through path
+    assert count(loop + "\ts_branch .LBB0_2\n" + mul50 + ".LBB0_2:\n\ts_endpgm\n") == 0  # an unconditional branch does not fall through

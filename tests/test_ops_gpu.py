@@ -180,6 +180,32 @@ def test_adaptive_residual_mix(dt, case):
         assert pad_part(out, c).abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("dt", list(DTYPES))
+@pytest.mark.parametrize("c", [48, 96, 192, 384])
+@pytest.mark.parametrize("alpha,wscale", [(-100.0, 1.0), (-100.0, 150.0), (100.0, 150.0), (0.37, 150.0)])
+def test_adaptive_residual_mix_saturated(dt, c, alpha, wscale):
+    """sigmoid(alpha) and the gate's sigmoid at the ends of their ranges (model.py:833-837).  alpha = -100 makes 1 / sigmoid(alpha) =
+    1 + e^100 overflow float32; the blend folds that factor into the gate's reciprocal (blend_(), mz_device.h) and the host keeps it
+    finite, so that the result is x as in the reference and never NaN -- also where the gate saturates (150 x weights: |beta| reaches a
+    few hundred, e^-beta flushes to 0 or overflows).  Every mix kernel family (C = 48 / 96: general 1x1 kernel, 192: mix16b, 384: mix16)."""
+    dtype = DTYPES[dt]
+    B, H, W = 1, 9, 21
+    x = q(rnd((B, c, H, W), 7), dtype)
+    z = q(rnd((B, c, H, W), 8), dtype)
+    w = q(wscale * wrnd((c, 2 * c, 1, 1), 9), dtype)
+    out = alloc_act(B, c, H, W, dtype)
+    op_conv(dtype, 3, to_act(x, dtype), to_act(z, dtype), w, alpha, out, B, H, W, 2 * c, c)
+    got = from_act(out, c)
+    assert torch.isfinite(got).all()
+    want = oracle.residual_mix(x, z, w, torch.tensor(alpha))
+    if alpha < -50:
+        assert torch.equal(got, x)  # sigmoid(-100) = 4e-44: the mix returns its first input
+    if dt == "f32" and wscale > 1:  # beta itself carries ~1e-4 of summation-order noise at this weight scale
+        assert (got - want).abs().max().item() <= 2e-4
+    else:
+        assert_op_close(got, want, dt)
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("wgs", ["", "8"])
 @pytest.mark.parametrize("case", [(1, 9, 40), (2, 33, 65), (3, 16, 16)])

@@ -492,7 +492,9 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     //      (PackArgs::frag16 = 2), so a pair of x fragments IS a B operand too -- x is fetched once; the 36 KB of gate weights
     //      stay in LDS for the whole launch;
     //   D: blend x + sigmoid(alpha) sigmoid(beta) (z - x) into the accumulator registers, then the three entries as usual.
-    // The arithmetic is conv3s_kernel<.., FUSE>'s, operation for operation (identical bits).
+    // The arithmetic is conv3s_kernel<.., FUSE>'s, operation for operation, EXCEPT the summation order of the x half of the gate inside a
+    // 32-wide K step (accumulator-row order here, plane order there): equal to <= 1 ulp of the output, >= 98 % bit-equal
+    // (tests/test_conv3r_gpu.py); which of the two runs therefore depends on channel counts only, never on H or W (mz_host.cpp).
     auto fuse_x = [&](auto pf_tag) __attribute__((always_inline)) {  // request x of pixel fragment pf
         constexpr int pf = decltype(pf_tag)::value;
         const bool inside = e_y + pf / 3 < a.H && e_c + 16 * (pf % 3) < a.W;

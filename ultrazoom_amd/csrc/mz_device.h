@@ -289,6 +289,20 @@ __device__ __forceinline__ void tile_rc_s(const ConvArgs& a, int trem, int& tyi,
     tyi = 4 * br + rem - txi * rows;
 }
 
+// ---- 16-byte buffer store whose offset travels in an SGPR, with the wait states gfx950 needs behind it PINNED -----------------------
+// A 12- / 16-byte store reads its data registers late: a vector instruction that overwrites one of them right behind the store
+// corrupts what reaches memory (measured in isolation: csrc/mz_probe.hip, tests/test_store_hazard_gpu.py,
+// profiles/r04_store_hazard_probe.json).  For stores with soffset 0 / global stores hipcc's hazard recogniser inserts a wait state
+// itself; for THIS form (soffset in a register) it inserts none.  Every such store in the kernels goes through this helper: the
+// store, then `s_nop 1` (two wait states: one more than the probe found necessary), fenced so that the scheduler cannot move
+// anything between them.  tools/asm_store_hazard.py re-checks the listings of every build (tests/test_kernel_resources.py).
+__device__ __forceinline__ void store16_soff(const u32x4& v, const __amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voffset, soffset, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

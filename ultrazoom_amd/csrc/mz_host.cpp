@@ -589,6 +589,14 @@ static int persistent_workgroups(const Knobs& k) {
     return g_dev_cus[dev];
 }
 
+// 1 / sigmoid(alpha) = 1 + e^-alpha for blend_() (mz_device.h), which folds the scale into the reciprocal of the gate's sigmoid:
+// rcp(fma(e^-beta, inv_s, inv_s)).  Kept finite: for alpha < -88.7 the exact value overflows to +inf and fma(0, inf, inf) (a gate
+// whose e^-beta flushed to 0) would be NaN where the reference (model.py:833-837) returns x; with FLT_MAX the weight is ~0 instead.
+static float inv_sigmoid(float alpha) {
+    const float v = 1.0f + std::exp(-alpha);
+    return std::isfinite(v) ? v : 3.402823466e+38f;
+}
+
 struct Runner {
     mz_handle* h;
     hipStream_t s;
@@ -711,8 +719,7 @@ struct Runner {
                 a.x_via_lds = (a.mix_pieces * 1024 + 8 * ncx * 1024 <= 2 * slot) ? 1 : 0;
             }
             a.mix_scale = 1.0f / (1.0f + std::exp(-alpha));
-        a.inv_mix_scale = 1.0f + std::exp(-alpha);
-            a.inv_mix_scale = 1.0f + std::exp(-alpha);
+            a.inv_mix_scale = inv_sigmoid(alpha);
             extra_flops = 2.0 * (double)B * H * W * 2.0 * c.cout * c.cout;
         }
         const double sz = dtype_size(dtype);
@@ -740,11 +747,10 @@ struct Runner {
                       mixf && mixf->packed16r && (mixf->cp0 + 31) / 32 == c.nt && persist_wgs > 0 && c.nchunks16 >= 6 && a.p0 % 4 == 0 &&
                       c.nchunks16 * 32 * 100 <= c.cp0 * (100 + knobs.kpad_pct) && (double)H * W * 64.0 < 4294967296.0 &&
                       12.0 * H * W * 16.0 < 4294967296.0;
-        if (use_rf) {
-            const long long padq = (long long)((H + 7) / 8 * 8) * ((W + 47) / 48 * 48);
-            const long long pads = (long long)a.tiles_y * th * a.tiles_x * tw;
-            use_rf = padq <= pads;
-        }
+        // (NOT a function of H and W: this kernel and conv3s_kernel<.., FUSE> sum the x half of the gate in different orders inside a
+        // 32-wide K step -- equal to <= 1 ulp, not bit for bit -- and a tile of upscale_tiled() must run the kernel the whole image runs,
+        // or "tiled == untiled bit for bit" (ultrazoom_amd/tiling.py) breaks.  The plain variants above ARE bit-identical to
+        // conv3s_kernel, so their choice may follow the padded-pixel count.)
         if (use_rf) {
             a.tiles_x = (W + 47) / 48; a.tiles_y = (H + 7) / 8;
             a.mtiles = B * a.tiles_x * a.tiles_y;
@@ -827,7 +833,7 @@ struct Runner {
         a.cp_out = pad16(c.cout);
         a.p_out = a.cp_out * sz / 16;
         a.mix_scale = 1.0f / (1.0f + std::exp(-alpha));
-        a.inv_mix_scale = 1.0f + std::exp(-alpha);
+        a.inv_mix_scale = inv_sigmoid(alpha);
         const bool mix16 = c.packed16 != nullptr && knobs.mix16 &&
                            (double)npix * c.cp0 * sz < 4294967296.0;  // 32-bit buffer offsets inside each tensor
         int mix16b_wgs = knobs.persist > 0 ? knobs.persist : 0;  // persistent (also under MZ_NO_PERSIST=1: it has no per-tile form)
