@@ -166,6 +166,11 @@ int mz_profile_read(mz_handle* h, double* conv_ms, double* conv_flops, double* c
  * (tools/stamp_probe*.py); returns -1 when it does not exist.  No reference counterpart. */
 int mz_debug_read(unsigned long long* host_dst);
 
+/* Kernel family of the calling thread's most recent convolution / mix launch ("conv3r", "conv3r_8x40", "conv3r_fused", "conv3t",
+ * "conv3t_fused", "conv3q", "conv3s", "conv3s_fused", "conv3p", "conv3w", "conv3w_fused", "conv_kernel", "mix16", "mix16b",
+ * "conv_kernel_mix"): lets a test that compares two kernels assert that it really ran both.  No reference counterpart. */
+const char* mz_debug_last_kernel(void);
+
 /* Hardware probe (ultrazoom_amd/csrc/mz_probe.hip; tests/test_store_hazard_gpu.py): on every CU, 16-byte buffer stores each followed --
  * `wait_states` (0, 1, 2) wait states later -- by a vector instruction that overwrites data register `dword` (0..3) of the store:
  * follower 0 v_mov_b32, 1 v_mul_f32, 2 v_cvt_pk_bf16_f32, 3 v_exp_f32, 4 v_pk_mul_f32, 5 v_mfma_f32_16x16x32_bf16;

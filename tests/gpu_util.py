@@ -102,3 +102,10 @@ def op_conv(dtype, kind, in0, in1, w, alpha, out, B, H, W, cin, cout, Hout=0, Wo
         )
     )
     torch.cuda.synchronize()
+
+
+def last_kernel() -> str:
+    """Kernel family of the most recent convolution / mix launch of this thread (mz_debug_last_kernel)."""
+    lib = _ffi.lib()
+    lib.mz_debug_last_kernel.restype = ctypes.c_char_p
+    return lib.mz_debug_last_kernel().decode()

@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from gpu_util import DTYPES, alloc_act, assert_op_close, from_act, op_conv, op_excess, op_excess_map, pad_part, q, to_act
+from gpu_util import DTYPES, alloc_act, assert_op_close, from_act, last_kernel, op_conv, op_excess, op_excess_map, pad_part, q, to_act
 from oracle import mewzoom_oracle as oracle
 from ultrazoom_amd.synth import hash_uniform
 
@@ -40,7 +40,24 @@ R_CASES = [
     (1, 135, 240, 192, 96, 1, 0),  # the level-4 geometry of cfg3 (5 tiles per row, 17 tile rows)
     (1, 24, 50, 96, 80, 1, 8),     # Cout = 80: the N tile's last plane pair does not exist (range-checked stores)
     (1, 32, 96, 224, 96, 1, 8),    # seven chunks
+    # widths that 40 divides better than 48: the 8 x 40 tile (five pixel fragments per wave, fragment 2 straddles the wave's two rows)
+    (1, 8, 40, 96, 96, 1, 0),      # ONE 8 x 40 tile
+    (1, 16, 80, 96, 96, 0, 8),     # four tiles on eight workgroups
+    (2, 67, 120, 384, 192, 1, 8),  # cfg2's level-4 geometry (67 x 120: 9 x 3 tiles), twelve chunks, two N tiles
+    (3, 23, 117, 96, 96, 1, 8),    # ragged in both directions; three chunks: 15 entries as 3 + 3, 3 + 3, 3 + 0
+    (1, 30, 200, 192, 288, 0, 16), # six chunks (1 + 2 entries per chunk over five of them), three N tiles
+    (1, 9, 79, 160, 96, 1, 8),     # five chunks
 ]
+
+
+def expected_r_kernel(H, W):
+    """The host's choice (mz_host.cpp, Runner::conv3): conv3r_kernel in the tile geometry that pads fewer pixels (8 x 40 or 8 x 48), unless
+    conv3s_kernel's 8 x 64 / 16 x 32 tiles pad fewer still."""
+    up = lambda v, m: -(-v // m) * m
+    pads = min(up(H, 8) * up(W, 64), up(H, 16) * up(W, 32))
+    pad48, pad40 = up(H, 8) * up(W, 48), up(H, 8) * up(W, 40)
+    geo1 = pad40 < pad48
+    return ("conv3r_8x40" if geo1 else "conv3r") if (pad40 if geo1 else pad48) <= pads else "conv3s"
 
 
 def run(dtype, kind, x_act, w, out_shape, args, env, monkeypatch, wgs):
@@ -74,6 +91,10 @@ def test_conv3r_matches_oracle_and_conv3s(dt, case, monkeypatch):
             monkeypatch.setenv("MZ_PERSIST_WGS", str(wgs))
         op_conv(dtype, 0, xa, None, w, 0.0, out, B, H, W, cin, cout, silu=silu)
         outs[name] = out
+        if name == "s":  # (Cin = 112 pads K by 14 %: the 32x32x16 kernel with exact 16-channel chunks takes it)
+            assert last_kernel() == ("conv3s" if cin % 32 == 0 else "conv3p"), last_kernel()
+        elif cin % 32 == 0:  # (Cin = 112: two planes in the last chunk -> the host keeps conv3r out)
+            assert last_kernel() == expected_r_kernel(H, W), (last_kernel(), H, W)
     want = F.conv2d(x, w, padding=1)
     if silu:
         want = F.silu(want)
@@ -83,7 +104,9 @@ def test_conv3r_matches_oracle_and_conv3s(dt, case, monkeypatch):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
-@pytest.mark.parametrize("shape", [(2, 40, 70, 96, 384, 81, 140), (1, 30, 100, 96, 192, 60, 200), (1, 16, 48, 128, 96, 33, 97)])
+@pytest.mark.parametrize("shape", [(2, 40, 70, 96, 384, 81, 140), (1, 30, 100, 96, 192, 60, 200), (1, 16, 48, 128, 96, 33, 97),
+                                   # 8 x 40 tiles (W = 120, 80, 37): the straddling fragment's sub-pixel store
+                                   (2, 67, 120, 384, 768, 135, 240), (1, 16, 80, 96, 384, 32, 160), (1, 20, 37, 96, 192, 41, 75)])
 def test_conv3r_subpixel(dt, shape, monkeypatch):
     dtype = DTYPES[dt]
     B, H, W, cin, cout, Hout, Wout = shape  # 96 -> 4 x 96 of the cfg3 head; 96 -> 4 x 48; 128 -> 4 x 24 (N tile spans all four sub-pixels)

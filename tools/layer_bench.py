@@ -17,16 +17,17 @@ if os.environ.get("LAYER_BENCH_VARIANTS"):   # e.g. LAYER_BENCH_VARIANTS='{"a": 
     VARIANTS = json.loads(os.environ["LAYER_BENCH_VARIANTS"])
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 workload = sys.argv[2] if len(sys.argv) > 2 else "cfg3"
+batch = int(os.environ.get("LAYER_BENCH_BATCH", "0"))
 if workload == "cfg2":
     cfg = MODELS["2x48"]
-    x = synth_image(8, 540, 960, seed=1000).to("cuda", torch.bfloat16)
+    x = synth_image(batch or 8, 540, 960, seed=1000).to("cuda", torch.bfloat16)
 else:
     cfg = MODELS["4x96"]
-    x = synth_image(3, 1080, 1920, seed=1000).to("cuda", torch.bfloat16)
+    x = synth_image(batch or 3, 1080, 1920, seed=1000).to("cuda", torch.bfloat16)
 sd = synth_state_dict(parameter_shapes(cfg), seed=1234)
 models = {}
 for name, env in VARIANTS.items():
-    for k in ("MZ_Q", "MZ_NO_Q", "MZ_NO_R", "MZ_NO_BLK4", "MZ_KPAD_PCT"):
+    for k in ("MZ_Q", "MZ_NO_Q", "MZ_NO_R", "MZ_NO_T", "MZ_NO_GEO40", "MZ_NO_BLK4", "MZ_KPAD_PCT"):
         os.environ.pop(k, None)
     os.environ.update(env)
     m = MewZoom(**cfg); m.load_state_dict(sd); m = m.to("cuda", torch.bfloat16).eval()

@@ -47,13 +47,28 @@
 namespace mz {
 namespace r3 {
 
-constexpr int TH = 8, TW = 48;
-constexpr int ROWW = 50;
-constexpr int NPIX = 10 * ROWW;      // 500 halo pixels
+// Pixel tile of a workgroup: 8 rows, wave w owns rows 2 w and 2 w + 1.  GEO 0: 8 x 48, six pixel fragments per wave (three per row);
+// GEO 1: 8 x 40, five pixel fragments per wave -- fragment 2 STRADDLES the wave's two rows (lanes c < 8: row 0, columns 32 + c; lanes
+// c >= 8: row 1, columns c - 8), which costs one more per-lane LDS base and per-lane store offset and nothing else: widths like 120
+// (cfg2's level 4: 67 x 120) that 48 does not divide lose 7.5 % of their MFMAs to padded pixels instead of 29 %.  Both halo images
+// are padded to 512 entries per plane (eight DMA pieces), so the LDS map and the loader role are the same.
+constexpr int TH = 8;
+template <int GEO> struct Geo {
+    static_assert(GEO == 0 || GEO == 1, "8 x 48 or 8 x 40");
+    static constexpr int TW = GEO == 0 ? 48 : 40;
+    static constexpr int NPF = GEO == 0 ? 6 : 5;   // pixel fragments per wave
+    static constexpr int ROWW = TW + 2;
+    static constexpr int NPIX = 10 * ROWW;         // 500 / 420 halo pixels
+    static constexpr int DIV_MAGIC = GEO == 0 ? 1311 : 1561;  // (p * magic) >> 16 = p / ROWW for p < 512
+    static constexpr int X0 = 3, X1 = NPF - 3;     // pixel fragments of the next tap requested in a tap's first / second group
+    // position of pixel fragment pf relative to the lane's pixel c of the wave's first row; STRADDLE: per lane (see above)
+    static constexpr bool straddle(int pf) { return GEO == 1 && pf == 2; }
+    static constexpr int dy(int pf) { return GEO == 0 ? pf / 3 : (pf >= 3 ? 1 : 0); }
+    static constexpr int dx(int pf) { return GEO == 0 ? 16 * (pf % 3) : (pf < 2 ? 16 * pf : (pf == 2 ? 0 : 8 + 16 * (pf - 3))); }
+};
 constexpr int PLANE_ENT = 512;       // padded: 4 planes = 32 whole DMA instructions
 constexpr int A_PLANE = PLANE_ENT * 16;
 constexpr int A_SLOT = 4 * A_PLANE;  // 32 KB
-constexpr int NPF = 6;               // pixel fragments per wave: 2 rows x 3
 constexpr int NT = 3, NF = 6, BN = 96;
 constexpr int NG = 9 * NT;           // groups per 32-channel chunk
 constexpr int B_BASE = 2 * A_SLOT;
@@ -71,12 +86,14 @@ template <int NSEG> struct Seg {
 };
 
 // byte offset of pixel fragment pf of tap (dy, dx) inside one plane of the halo image, relative to the wave's first row
-template <int TAP, int PF> constexpr int a_off() {
+// (straddling fragment: relative to the lane's SECOND base, which holds its per-lane displacement)
+template <int GEO, int TAP, int PF> constexpr int a_off() {
+    using GG = Geo<GEO>;
     constexpr int DY = TAP / 3, DX = TAP % 3;
-    return ((DY + PF / 3) * ROWW + DX + 16 * (PF % 3)) * 16;
+    return ((DY + GG::dy(PF)) * GG::ROWW + DX + GG::dx(PF)) * 16;
 }
 
-struct Frag {
+template <int NPF> struct Frag {
     u32x4 x[2][NPF];  // [tap parity][pixel fragment]
     u32x4 w[3][2];    // [group % 3][channel fragment of the pair]: requested TWO groups (24 MFMAs) ahead
 };
@@ -85,9 +102,16 @@ template <int N> __device__ __forceinline__ void wait_w(u32x4& w0, u32x4& w1) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(w0), "+v"(w1) : "n"(N) : "memory");
 }
 template <int N>
-__device__ __forceinline__ void wait_wx(u32x4& w0, u32x4& w1, u32x4& x0, u32x4& x1, u32x4& x2, u32x4& x3, u32x4& x4, u32x4& x5) {
+__device__ __forceinline__ void wait_wx(u32x4& w0, u32x4& w1, u32x4 (&x)[6]) {
     asm volatile("s_waitcnt lgkmcnt(%8)"
-                 : "+v"(w0), "+v"(w1), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5)
+                 : "+v"(w0), "+v"(w1), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5])
+                 : "n"(N)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_wx(u32x4& w0, u32x4& w1, u32x4 (&x)[5]) {
+    asm volatile("s_waitcnt lgkmcnt(%7)"
+                 : "+v"(w0), "+v"(w1), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4])
                  : "n"(N)
                  : "memory");
 }
@@ -95,15 +119,22 @@ __device__ __forceinline__ void wait_wx(u32x4& w0, u32x4& w1, u32x4& x0, u32x4& 
 // LDS read addresses of one lane: halo image of the current / next chunk, weight slot of the current / next step
 struct Bases {
     uint32_t a_cur, a_nxt, b_cur, b_nxt;
+    uint32_t a2_cur, a2_nxt;  // GEO 1: the same for the straddling pixel fragment (unused, and optimised away, otherwise)
 };
+template <int GEO, int TAP, int PF> __device__ __forceinline__ u32x4 read_x(const Bases& bs, const bool next_image) {
+    if constexpr (Geo<GEO>::straddle(PF)) return lds_read128<a_off<GEO, TAP, PF>()>(next_image ? bs.a2_nxt : bs.a2_cur);
+    else return lds_read128<a_off<GEO, TAP, PF>()>(next_image ? bs.a_nxt : bs.a_cur);
+}
 
 // Group GC of a chunk: tap t = GC / 3, channel-fragment pair n = GC % 3: 12 MFMAs.  While they issue, the wave requests the
 // weight pair of group GC + 2 and (n < 2) three pixel fragments of tap t + 1 -- from the NEXT slot / halo image where the
 // group or tap index runs past this segment / chunk.  Tap t reads pixel buffer (t + XP) & 1 (a chunk has 9 taps, so the
 // parity of a chunk's tap 0 flips from chunk to chunk; XP = chunk index & 1 inside the tile).
-template <class TT, int NSEG, int GC, int XP, bool ZERO_C, int M>
-__device__ __forceinline__ void group_mfmas(f32x4 (&acc)[NPF][NF], Frag& f, const Bases& bs) {
-    if constexpr (M < 12) {
+template <class TT, int NSEG, int GEO, int GC, int XP, bool ZERO_C, int M>
+__device__ __forceinline__ void group_mfmas(f32x4 (&acc)[Geo<GEO>::NPF][NF], Frag<Geo<GEO>::NPF>& f, const Bases& bs) {
+    using GG = Geo<GEO>;
+    constexpr int NPF = GG::NPF;
+    if constexpr (M < 2 * NPF) {
         using S = Seg<NSEG>;
         constexpr int t = GC / 3, n = GC % 3, xp = (t + XP) & 1, xq = xp ^ 1;
         constexpr int sg = S::of(GC);
@@ -116,7 +147,7 @@ __device__ __forceinline__ void group_mfmas(f32x4 (&acc)[NPF][NF], Frag& f, cons
         // second time (18 -> 16 changes per tap instead of 36).  Same FLOPs, same registers, same sums (every accumulator still sees
         // its MFMAs in K order), but the chip is power-limited in this loop and holds a higher clock: deep layers -2 %, whole forward
         // -1 % against the channel-major raster order (tools/microbench/mb_order.hip).
-        constexpr int pf = (n & 1) ? 5 - M / 2 : M / 2, k = ((M / 2) & 1) ? 1 - (M & 1) : (M & 1);
+        constexpr int pf = (n & 1) ? NPF - 1 - M / 2 : M / 2, k = ((M / 2) & 1) ? 1 - (M & 1) : (M & 1);
         if constexpr (ZERO_C) {  // a tile's first tap WRITES the accumulators (C = 0): nobody has to clear 144 registers per tile
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
             if constexpr (TT::IS_BF16)
@@ -131,38 +162,39 @@ __device__ __forceinline__ void group_mfmas(f32x4 (&acc)[NPF][NF], Frag& f, cons
             f.w[T % 3][M] = lds_read128<(2 * t_idx + M) * 1024>(t_here ? bs.b_cur : bs.b_nxt);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (n < 2 && M >= 2 && M < 5) {
-            constexpr int pfn = 3 * n + (M - 2);
-            if constexpr (t + 1 < 9) f.x[xq][pfn] = lds_read128<a_off<t + 1, pfn>()>(bs.a_cur);
-            else f.x[xq][pfn] = lds_read128<a_off<0, pfn>()>(bs.a_nxt);
+        if constexpr (n < 2 && M >= 2 && M < 2 + (n == 0 ? GG::X0 : GG::X1)) {
+            constexpr int pfn = GG::X0 * n + (M - 2);
+            if constexpr (t + 1 < 9) f.x[xq][pfn] = read_x<GEO, (t + 1 < 9 ? t + 1 : 0), pfn>(bs, false);
+            else f.x[xq][pfn] = read_x<GEO, 0, pfn>(bs, true);
             __builtin_amdgcn_sched_barrier(0);
         }
-        group_mfmas<TT, NSEG, GC, XP, ZERO_C, M + 1>(acc, f, bs);
+        group_mfmas<TT, NSEG, GEO, GC, XP, ZERO_C, M + 1>(acc, f, bs);
     }
 }
 
 // groups [G, GE) of one step
-template <class TT, int NSEG, int G, int GE, int XP>
-__device__ __forceinline__ void groups(f32x4 (&acc)[NPF][NF], Frag& f, const Bases& bs, bool first) {
+template <class TT, int NSEG, int GEO, int G, int GE, int XP>
+__device__ __forceinline__ void groups(f32x4 (&acc)[Geo<GEO>::NPF][NF], Frag<Geo<GEO>::NPF>& f, const Bases& bs, bool first) {
+    using GG = Geo<GEO>;
     if constexpr (G < GE) {
         constexpr int t = G / 3, n = G % 3;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (G < 3 && XP == 0) {  // tap 0 of a chunk that may be the tile's first (a tile starts on parity 0)
-            if (first) group_mfmas<TT, NSEG, G, XP, true, 0>(acc, f, bs);
-            else group_mfmas<TT, NSEG, G, XP, false, 0>(acc, f, bs);
+            if (first) group_mfmas<TT, NSEG, GEO, G, XP, true, 0>(acc, f, bs);
+            else group_mfmas<TT, NSEG, GEO, G, XP, false, 0>(acc, f, bs);
         } else {
-            group_mfmas<TT, NSEG, G, XP, false, 0>(acc, f, bs);
+            group_mfmas<TT, NSEG, GEO, G, XP, false, 0>(acc, f, bs);
         }
         // what the NEXT group needs (also across the end of this step: the stream continues behind the barrier).  LDS reads
-        // return in order.  Reads requested per group: n = 0, 1: two weight + three pixel fragments, n = 2: two weight fragments.
+        // return in order.  Reads requested per group: n = 0: two weight + X0 pixel fragments, n = 1: two + X1, n = 2: two weight fragments.
         constexpr int wn = (G + 1) % 3, xn = (t + 1 + XP) & 1;
         if constexpr (n == 2)
-            wait_wx<2>(f.w[wn][0], f.w[wn][1], f.x[xn][0], f.x[xn][1], f.x[xn][2], f.x[xn][3], f.x[xn][4], f.x[xn][5]);
+            wait_wx<2>(f.w[wn][0], f.w[wn][1], f.x[xn]);
         else if constexpr (n == 1)
-            wait_w<8>(f.w[wn][0], f.w[wn][1]);
+            wait_w<GG::X0 + 2 + GG::X1>(f.w[wn][0], f.w[wn][1]);  // (the weights of group n = 2 were requested at the head of group n = 0)
         else
-            wait_w<5>(f.w[wn][0], f.w[wn][1]);
-        groups<TT, NSEG, G + 1, GE, XP>(acc, f, bs, first);
+            wait_w<2 + GG::X0>(f.w[wn][0], f.w[wn][1]);
+        groups<TT, NSEG, GEO, G + 1, GE, XP>(acc, f, bs, first);
     }
 }
 
@@ -273,11 +305,15 @@ __device__ __forceinline__ void blend_pair_to(float& o0, float& o1, const float 
 
 // EPI: EPI_STORE (SILU: with the activation), EPI_D2S, EPI_FUSEDMIX (needs NSEG = 3).  SILU is a template parameter: a run-time
 // branch around the activation made hipcc copy every value twice more on its way through the epilogue.
-template <class TT, int NSEG, int EPI, bool SILU>
+template <class TT, int NSEG, int EPI, bool SILU, int GEO = 0>
 __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     using namespace r3;
     using S = Seg<NSEG>;
+    using GG = Geo<GEO>;
+    constexpr int NPF = GG::NPF, TW = GG::TW, ROWW = GG::ROWW, NPIX = GG::NPIX;
+    constexpr int NE = NPF * NT;  // 16-byte epilogue entries per wave and tile
     constexpr bool FUSE = EPI == EPI_FUSEDMIX;
+    static_assert(!FUSE || GEO == 0, "the fused variant is built for the 8 x 48 tile");
     constexpr int B_SLOT = S::SLOT;
     static_assert(!FUSE || NSEG == 3, "the gate weights need the LDS that three weight segments leave free");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -320,7 +356,7 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     auto next3 = [](int v) __attribute__((always_inline)) { return v == 2 ? 0 : v + 1; };
 
     f32x4 acc[NPF][NF];
-    Frag f;
+    Frag<NPF> f;
     Done done = {0, 0};
     RS_DECL;  // diagnostic builds: counters 0/1 = K-loop cycles / tiles; 4 c .. 4 c + 3 = DMA issue / epilogue / vmcnt wait / barrier of loader
               // step class c = 1 + 2 (epilogue step) + (not a chunk's first step), 20 + c = steps of the class
@@ -352,7 +388,7 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int p = 64 * (wq + 4 * j) + lane_;
-            const int py = (p * 1311) >> 16, px = p - py * ROWW;  // p / 50 for p < 512
+            const int py = (p * GG::DIV_MAGIC) >> 16, px = p - py * ROWW;  // p / ROWW for p < 512
             uint32_t o = ((uint32_t)py * (uint32_t)a.W + (uint32_t)px) * 16u + delta;
             if (!interior) {
                 const int gy = y0 - 1 + py, gx = x0 - 1 + px;
@@ -394,6 +430,8 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     uint32_t x_lane = 0;           // FUSE: offset of the lane's 8 bytes of channel fragment 0 relative to e_pix
     uint32_t e_pix = 0, eoff[NT] = {0, 0, 0};
     int e_c = 0, e_y = 0;
+    [[maybe_unused]] int e_sdy = 0, e_sdx = 0;     // GEO 1: row / column displacement of the lane's pixel of the straddling fragment
+    [[maybe_unused]] uint32_t e_soff = 0;          // ... and its byte offset relative to e_pix
     auto epi_setup = [&]() __attribute__((always_inline)) {
         const int lane_ = lane_now();
         const int g = lane_ >> 4, c = lane_ & 15;
@@ -403,11 +441,16 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         const int d_nbase = done.nt * BN;
         e_c = d_x0 + c;
         e_y = d_y0 + 2 * wq;
+        if constexpr (GEO == 1) {
+            e_sdy = c >= 8 ? 1 : 0;
+            e_sdx = c >= 8 ? -8 : 32;
+        }
         if constexpr (EPI == EPI_D2S) {
             const long long plane_o = (long long)a.Hout * a.Wout * 16;
             orsrc = __builtin_amdgcn_make_buffer_rsrc((char*)a.out + (long long)d_b * a.p_out * plane_o, 0,
                                                       (int)(uint32_t)(a.p_out * plane_o), 0x00020000);
             e_pix = ((uint32_t)(2 * e_y) * (uint32_t)a.Wout + (uint32_t)(2 * e_c)) * 16u;
+            if constexpr (GEO == 1) e_soff = (uint32_t)((2 * e_sdy * a.Wout + 2 * e_sdx) * 16);
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const int nch = d_nbase + (4 * n + lane_cu) * 8;
@@ -423,6 +466,7 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
             orsrc = __builtin_amdgcn_make_buffer_rsrc((char*)a.out + ((long long)d_b * a.p_out + p_first) * plane_o, 0,
                                                       (int)(uint32_t)(planes * plane_o), 0x00020000);
             e_pix = ((uint32_t)e_y * (uint32_t)a.W + (uint32_t)e_c) * 16u;
+            if constexpr (GEO == 1) e_soff = (uint32_t)((e_sdy * a.W + e_sdx) * 16);
 #pragma unroll
             for (int n = 0; n < NT; ++n) eoff[n] = (uint32_t)(4 * n + lane_cu) * (uint32_t)plane_o;  // planes that do not exist fall out of range
             if constexpr (FUSE) {
@@ -478,10 +522,16 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     auto epi_store = [&](auto e_tag, const u32x4& o) __attribute__((always_inline)) {
         constexpr int E = decltype(e_tag)::value;
         constexpr int pf = E / NT, n = E % NT;
-        const bool inside = e_y + pf / 3 < a.H && e_c + 16 * (pf % 3) < a.W;
+        bool inside;
         uint32_t off;
-        if constexpr (EPI == EPI_D2S) off = e_pix + (uint32_t)(2 * (pf / 3)) * (uint32_t)a.Wout * 16u + (uint32_t)(32 * (pf % 3)) * 16u + eoff[n];
-        else off = e_pix + (uint32_t)(pf / 3) * (uint32_t)a.W * 16u + (uint32_t)(16 * (pf % 3)) * 16u + eoff[n];
+        if constexpr (GG::straddle(pf)) {
+            inside = e_y + e_sdy < a.H && e_c + e_sdx < a.W;
+            off = e_pix + e_soff + eoff[n];
+        } else {
+            inside = e_y + GG::dy(pf) < a.H && e_c + GG::dx(pf) < a.W;
+            if constexpr (EPI == EPI_D2S) off = e_pix + (uint32_t)(2 * GG::dy(pf)) * (uint32_t)a.Wout * 16u + (uint32_t)(2 * GG::dx(pf)) * 16u + eoff[n];
+            else off = e_pix + (uint32_t)GG::dy(pf) * (uint32_t)a.W * 16u + (uint32_t)GG::dx(pf) * 16u + eoff[n];
+        }
         if (!inside || eoff[n] == 0xffffffffu) off = 0xffffffffu;
         __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, (int)off, 0, 0);
     };
@@ -497,9 +547,9 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     // (tests/test_conv3r_gpu.py); which of the two runs therefore depends on channel counts only, never on H or W (mz_host.cpp).
     auto fuse_x = [&](auto pf_tag) __attribute__((always_inline)) {  // request x of pixel fragment pf
         constexpr int pf = decltype(pf_tag)::value;
-        const bool inside = e_y + pf / 3 < a.H && e_c + 16 * (pf % 3) < a.W;
+        const bool inside = e_y + GG::dy(pf) < a.H && e_c + GG::dx(pf) < a.W;
         const long long plane_o = (long long)a.H * a.W * 16;
-        uint32_t off = e_pix + (uint32_t)(pf / 3) * (uint32_t)a.W * 16u + (uint32_t)(16 * (pf % 3)) * 16u + x_lane;
+        uint32_t off = e_pix + (uint32_t)GG::dy(pf) * (uint32_t)a.W * 16u + (uint32_t)GG::dx(pf) * 16u + x_lane;
         if (!inside) off = 0xffffffffu;
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
@@ -540,11 +590,18 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         u32x4 wa[NT], wb[NT];
         gate_reads<0, 0>(wa, mix_lane);
         gate_halves<TT, 0>(acc[pf], xb, f_zb, wa, wb, mix_lane);
+        // MFMA result -> VALU read is a software hazard (8 passes: 11 wait states) that hipcc does not see into inline asm for: the blend
+        // (blend_pair_to) reads beta from inline-asm chains.  In the tile loop a whole step lies between gate and blend; in the final
+        // epilogue they follow each other directly (conv3t_kernel met the stale read there).
+        asm volatile("s_nop 7\n\ts_nop 4" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
     };
     auto entry_whole = [&](auto e_tag) __attribute__((always_inline)) {
-        u32x4 o;
-        entry_words(e_tag, o);
-        epi_store(e_tag, o);
+        if constexpr (decltype(e_tag)::value < NE) {
+            u32x4 o;
+            entry_words(e_tag, o);
+            epi_store(e_tag, o);
+        }
     };
 
     auto zero_acc = [&]() __attribute__((always_inline)) {
@@ -557,19 +614,22 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     auto prime = [&](int wslot, int aslot) __attribute__((always_inline)) {
         const int lane_ = lane_now();
         const int g = lane_ >> 4, c = lane_ & 15;
-        const uint32_t ab = lds_base + aslot * A_SLOT + g * A_PLANE + ((2 * wq) * ROWW + c) * 16;
+        Bases pb;
+        pb.a_cur = pb.a_nxt = lds_base + aslot * A_SLOT + g * A_PLANE + ((2 * wq) * ROWW + c) * 16;
+        pb.a2_cur = pb.a2_nxt = pb.a_cur + (uint32_t)((c >= 8 ? ROWW - 8 : 32) * 16);  // (GEO 1: the straddling fragment)
+        pb.b_cur = pb.b_nxt = 0;
         const uint32_t bb = lds_base + B_BASE + wslot * B_SLOT + lane_ * 16;
-        f.x[0][0] = lds_read128<a_off<0, 0>()>(ab);
-        f.x[0][1] = lds_read128<a_off<0, 1>()>(ab);
-        f.x[0][2] = lds_read128<a_off<0, 2>()>(ab);
-        f.x[0][3] = lds_read128<a_off<0, 3>()>(ab);
-        f.x[0][4] = lds_read128<a_off<0, 4>()>(ab);
-        f.x[0][5] = lds_read128<a_off<0, 5>()>(ab);
+        f.x[0][0] = read_x<GEO, 0, 0>(pb, false);
+        f.x[0][1] = read_x<GEO, 0, 1>(pb, false);
+        f.x[0][2] = read_x<GEO, 0, 2>(pb, false);
+        f.x[0][3] = read_x<GEO, 0, 3>(pb, false);
+        f.x[0][4] = read_x<GEO, 0, 4>(pb, false);
+        if constexpr (NPF > 5) f.x[0][NPF - 1] = read_x<GEO, 0, NPF - 1>(pb, false);
         f.w[0][0] = lds_read128<0 * 1024>(bb);
         f.w[0][1] = lds_read128<1 * 1024>(bb);
         f.w[1][0] = lds_read128<2 * 1024>(bb);
         f.w[1][1] = lds_read128<3 * 1024>(bb);
-        wait_wx<0>(f.w[0][0], f.w[0][1], f.x[0][0], f.x[0][1], f.x[0][2], f.x[0][3], f.x[0][4], f.x[0][5]);
+        wait_wx<0>(f.w[0][0], f.w[0][1], f.x[0]);
         wait_w<0>(f.w[1][0], f.w[1][1]);
     };
 
@@ -677,7 +737,10 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     };
     // chunk iteration k of the plain variants; E0 = its first entry, N0 / N1 = entries of its first / second step
     auto loader_chunk = [&](auto e0_tag, auto n0_tag, auto n1_tag, auto last_tag, int k) __attribute__((always_inline)) {
-        constexpr int E0 = decltype(e0_tag)::value, N0 = decltype(n0_tag)::value, N1 = decltype(n1_tag)::value;
+        // (clamped to the NE entries a tile has: 18, or 15 with the five-fragment geometry)
+        constexpr int E0 = decltype(e0_tag)::value < NE ? decltype(e0_tag)::value : NE;
+        constexpr int N0 = decltype(n0_tag)::value < NE - E0 ? decltype(n0_tag)::value : NE - E0;
+        constexpr int N1 = decltype(n1_tag)::value < NE - E0 - N0 ? decltype(n1_tag)::value : NE - E0 - N0;
         if constexpr (NSEG == 2) {
             loader_step(ic<(N0 > 0)>{}, ic<E0>{}, ic<N0>{}, ic<0>{}, last_tag, k);
             loader_step(ic<(N1 > 0)>{}, ic<E0 + N0>{}, ic<N1>{}, ic<1>{}, last_tag, k);
@@ -762,6 +825,9 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         Bases bs;
         bs.a_cur = a_lane + us * A_SLOT;
         bs.a_nxt = a_lane + (us ^ 1) * A_SLOT;
+        const uint32_t a_str = (uint32_t)((c >= 8 ? ROWW - 8 : 32) * 16);  // GEO 1: the straddling fragment's displacement
+        bs.a2_cur = bs.a_cur + a_str;
+        bs.a2_nxt = bs.a_nxt + a_str;
         const uint32_t bl = lds_base + B_BASE + lane_ * 16;
         uint32_t b0 = bl + hs * B_SLOT, b1 = bl + next3(hs) * B_SLOT, b2 = bl + next3(next3(hs)) * B_SLOT;
         bs.b_cur = b0;
@@ -773,15 +839,16 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         };
         auto chunk = [&](auto xp_tag, bool first) __attribute__((always_inline)) {
             constexpr int XP = decltype(xp_tag)::value;
-            groups<TT, NSEG, S::start(0), S::start(1), XP>(acc, f, bs, first);
+            groups<TT, NSEG, GEO, S::start(0), S::start(1), XP>(acc, f, bs, first);
             step_tail();
-            groups<TT, NSEG, S::start(1), S::start(2), XP>(acc, f, bs, false);
+            groups<TT, NSEG, GEO, S::start(1), S::start(2), XP>(acc, f, bs, false);
             step_tail();
             if constexpr (NSEG == 3) {
-                groups<TT, NSEG, S::start(2), S::start(3), XP>(acc, f, bs, false);
+                groups<TT, NSEG, GEO, S::start(2), S::start(3), XP>(acc, f, bs, false);
                 step_tail();
             }
             const uint32_t v_ = bs.a_cur; bs.a_cur = bs.a_nxt; bs.a_nxt = v_;
+            if constexpr (GEO == 1) { const uint32_t v2_ = bs.a2_cur; bs.a2_cur = bs.a2_nxt; bs.a2_nxt = v2_; }
         };
         // The last groups of a tile request fragments of a "next chunk" this wave will not compute: they are waited for behind
         // the loop (the registers are reused by the loader role).
@@ -797,8 +864,8 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
             if (++kc >= nchunks) break;
         }
         asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(f.x[0][0]), "+v"(f.x[0][1]), "+v"(f.x[0][2]), "+v"(f.x[0][3]), "+v"(f.x[0][4]), "+v"(f.x[0][5]),
-                       "+v"(f.x[1][0]), "+v"(f.x[1][1]), "+v"(f.x[1][2]), "+v"(f.x[1][3]), "+v"(f.x[1][4]), "+v"(f.x[1][5])
+                     : "+v"(f.x[0][0]), "+v"(f.x[0][1]), "+v"(f.x[0][2]), "+v"(f.x[0][3]), "+v"(f.x[0][4]), "+v"(f.x[0][NPF - 1]),
+                       "+v"(f.x[1][0]), "+v"(f.x[1][1]), "+v"(f.x[1][2]), "+v"(f.x[1][3]), "+v"(f.x[1][4]), "+v"(f.x[1][NPF - 1])
                      :
                      : "memory");
         asm volatile("" : "+v"(f.w[0][0]), "+v"(f.w[0][1]), "+v"(f.w[1][0]), "+v"(f.w[1][1]), "+v"(f.w[2][0]), "+v"(f.w[2][1]));

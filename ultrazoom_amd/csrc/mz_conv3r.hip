@@ -7,20 +7,27 @@
 
 namespace mz {
 
-template <class TT, int NSEG, int EPI, bool SILU = false> static hipError_t r_launch(const ConvArgs& a, hipStream_t s) {
+template <class TT, int NSEG, int EPI, bool SILU = false, int GEO = 0> static hipError_t r_launch(const ConvArgs& a, hipStream_t s) {
     constexpr size_t lds = r3::Seg<NSEG>::lds_bytes(EPI == EPI_FUSEDMIX);
     static bool ready[16] = {};  // per device ordinal: the dynamic-LDS limit of this instantiation has been raised
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
     if (!ready[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3r_kernel<TT, NSEG, EPI, SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)conv3r_kernel<TT, NSEG, EPI, SILU, GEO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         ready[dev] = true;
     }
-    hipLaunchKernelGGL((conv3r_kernel<TT, NSEG, EPI, SILU>), dim3(a.persist), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((conv3r_kernel<TT, NSEG, EPI, SILU, GEO>), dim3(a.persist), dim3(512), lds, s, a);
     return hipGetLastError();
 }
 template <class TT> static hipError_t r_epi(const ConvArgs& a, hipStream_t s) {
+    if (a.geo == 1) {  // 8 x 40 pixel tiles (five pixel fragments per wave): plain / SiLU / sub-pixel stores
+        switch (a.epi) {
+            case EPI_STORE: return a.silu ? r_launch<TT, MZ_R_NSEG, EPI_STORE, true, 1>(a, s) : r_launch<TT, MZ_R_NSEG, EPI_STORE, false, 1>(a, s);
+            case EPI_D2S: return r_launch<TT, MZ_R_NSEG, EPI_D2S, false, 1>(a, s);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (a.epi) {
         case EPI_STORE: return a.silu ? r_launch<TT, MZ_R_NSEG, EPI_STORE, true>(a, s) : r_launch<TT, MZ_R_NSEG, EPI_STORE, false>(a, s);
         case EPI_D2S: return r_launch<TT, MZ_R_NSEG, EPI_D2S>(a, s);
@@ -29,9 +36,10 @@ template <class TT> static hipError_t r_epi(const ConvArgs& a, hipStream_t s) {
     }
 }
 
-// a.persist workgroups of 512 threads; a.tiles_x / tiles_y / mtiles describe 8 x 48 tiles; 96-channel N tiles; >= 3 chunks
+// a.persist workgroups of 512 threads; a.tiles_x / tiles_y / mtiles describe 8 x 48 (a.geo = 0) or 8 x 40 (a.geo = 1) tiles; 96-channel N
+// tiles; >= 3 chunks
 hipError_t launch_conv3r(int dtype, const ConvArgs& a, hipStream_t s) {
-    if (a.persist <= 0 || (a.persist & 7) || a.nchunks16 < 3) return hipErrorInvalidValue;
+    if (a.persist <= 0 || (a.persist & 7) || a.nchunks16 < 3 || a.geo < 0 || a.geo > 1) return hipErrorInvalidValue;
     switch (dtype) {
         case DT_BF16: return r_epi<TBF16>(a, s);
         case DT_F16: return r_epi<TF16>(a, s);

@@ -24,6 +24,8 @@ using namespace mz;
 // errors
 // ------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
+// kernel family of this thread's most recent convolution / mix launch (mz_debug_last_kernel(): the tests assert WHICH kernel they compare)
+static thread_local const char* g_last_kernel = "";
 static int fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -71,6 +73,8 @@ struct Knobs {
     int blk4 = 1;           // MZ_NO_BLK4=1: row-major tile walk inside an image (A/B of the L2 sharing of vertical halos)
     int q = 1;              // MZ_NO_Q=1: never use conv3q_kernel (one compute + one loader wave per SIMD, 8 x 48 tiles)
     int r = 1;              // MZ_NO_R=1: never use conv3r_kernel (conv3q's tile with role-alternating waves: epilogues under the next K loop)
+    int geo40 = 1;          // MZ_NO_GEO40=1: conv3r_kernel keeps its 8 x 48 tiles where 8 x 40 tiles would pad fewer pixels
+    int t = 1;              // MZ_NO_T=1: never use conv3t_kernel (the same structure for ONE N tile of <= 48 channels, 12 x 64 tiles)
 };
 static Knobs read_knobs() {
     Knobs k;
@@ -83,6 +87,8 @@ static Knobs read_knobs() {
     k.mix16b = getenv("MZ_NO_MIX16B") == nullptr;
     k.q = getenv("MZ_NO_Q") == nullptr;
     k.r = getenv("MZ_NO_R") == nullptr;
+    k.t = getenv("MZ_NO_T") == nullptr;
+    k.geo40 = getenv("MZ_NO_GEO40") == nullptr;
     k.blk4 = getenv("MZ_NO_BLK4") == nullptr;
     if (const char* e = getenv("MZ_KPAD_PCT")) k.kpad_pct = atoi(e);
     if (getenv("MZ_NO_PERSIST") != nullptr) k.persist = 0;
@@ -108,6 +114,9 @@ struct ConvW {
     size_t packed16_sz = 0;
     int nchunks16 = 0;
     void* packed16r = nullptr;  // fused gate weights once more, both halves in accumulator-row order (conv3r_kernel; PackArgs::frag16 = 2)
+    void* packed16t = nullptr;  // conv3t_kernel (one N tile of <= 48 channels): three 16-channel fragments per tap; SRC_MIXF: its gate (frag16 = 4)
+    size_t packed16t_sz = 0;
+    int nchunks16t = 0;
     bool set = false;
 };
 
@@ -149,6 +158,11 @@ static void plan_conv(ConvW& c, int dtype, int mode, int cout, int cin, int kh, 
     if (mode == MODE_CONV3 && dtype != DT_F32 && in_map == SRC_PLAIN && out_map != OUT_FINAL && c.nt <= 3) {
         c.nchunks16 = (c.cp0 + 31) / 32;
         c.packed16_sz = packed_bytes(c.taps, 2 * c.nt, c.ntiles, c.nchunks16);
+    }
+    // one N tile of 33..48 channels over whole 32-channel chunks: third packing, for conv3t_kernel (three fragments per tap)
+    if (mode == MODE_CONV3 && dtype != DT_F32 && in_map == SRC_PLAIN && out_map == OUT_PLAIN && c.n_logical_padded == 48 && c.cp0 % 32 == 0) {
+        c.nchunks16t = c.cp0 / 32;
+        c.packed16t_sz = packed_bytes(c.taps, 3, 1, c.nchunks16t);
     }
     // AdaptiveResidualMix with C = k * 192: second packing for mix16_kernel (192-channel N tiles = 12 fragments of 16)
     if (mode == MODE_GEMM1 && dtype != DT_F32 && in_map == SRC_CONCAT && cout % 192 == 0 && c0 == cout && c1 == cout) {
@@ -240,6 +254,7 @@ static void add_block(mz_handle* h, BlockW* b, const std::string& prefix, int c)
         if (h->dtype != DT_F32) {  // second packing for the fused epilogue of the 16x16x32 kernel: 2 nt K-steps x 2 nt fragments
             f.nchunks16 = (f.cp0 + 31) / 32 + f.nt;
             f.packed16_sz = packed_bytes(1, 2 * f.nt, 1, f.nchunks16);
+            if (f.cp0 == 48) f.packed16t_sz = packed_bytes(1, 3, 1, 3);  // conv3t_kernel's gate: three K steps x three fragments
         }
     }
     add_slot(h, prefix + ".convnet.conv1.weight", SK_CONV, {hr * c, c, 3, 3});
@@ -355,6 +370,8 @@ static void free_conv(ConvW& c) {
     c.packed16 = nullptr;
     if (c.packed16r) (void)hipFree(c.packed16r);
     c.packed16r = nullptr;
+    if (c.packed16t) (void)hipFree(c.packed16t);
+    c.packed16t = nullptr;
 }
 
 extern "C" int mz_destroy(mz_handle* h) {
@@ -409,7 +426,7 @@ static int pack_conv(ConvW& c, int dtype, const float* w_dev, hipStream_t s) {
     p.taps = c.taps; p.nt = c.nt; p.ntiles = c.ntiles; p.nchunks = c.nchunks;
     p.out_map = c.out_map; p.cq = c.cq; p.cq_p = c.cq_p;
     p.in_map = c.in_map; p.c0 = c.c0; p.cp0 = c.cp0; p.c1 = c.c1;
-    p.frag16 = 0;
+    p.frag16 = 0; p.nfr = 0;
     HIPCHK(launch_pack(p, s));
     if (c.packed16_sz) {
         if (!c.packed16) HIPCHK(hipMalloc(&c.packed16, c.packed16_sz));
@@ -426,6 +443,13 @@ static int pack_conv(ConvW& c, int dtype, const float* w_dev, hipStream_t s) {
             p.dst = c.packed16r; p.frag16 = 2;
             HIPCHK(launch_pack(p, s));
         }
+    }
+    if (c.packed16t_sz) {  // conv3t_kernel: three 16-channel fragments per tap (its gate: PackArgs::frag16 = 4)
+        if (!c.packed16t) HIPCHK(hipMalloc(&c.packed16t, c.packed16t_sz));
+        p.dst = c.packed16t; p.nt = c.nt; p.ntiles = 1; p.nfr = 3;
+        if (c.in_map == SRC_MIXF) { p.frag16 = 4; p.nchunks = 3; }
+        else { p.frag16 = 1; p.nchunks = c.nchunks16t; }
+        HIPCHK(launch_pack(p, s));
     }
     c.set = true;
     return MZ_OK;
@@ -730,17 +754,46 @@ struct Runner {
         bool q_common = use_s16 && !film_gamma && dtype != DT_F32 && c.nt == 3 && c.packed16 && (epi == EPI_STORE || epi == EPI_D2S) &&
                         persist_wgs > 0 && c.nchunks16 * 32 * 100 <= c.cp0 * (100 + knobs.kpad_pct) &&
                         (double)H * W * 64.0 < 4294967296.0;
-        if (q_common) {  // padded pixels of the 8 x 48 tiles against the better of the 8 x 64 / 16 x 32 tiles
-            const long long padq = (long long)((H + 7) / 8 * 8) * ((W + 47) / 48 * 48);
-            const long long pads = (long long)a.tiles_y * th * a.tiles_x * tw;
-            q_common = padq <= pads;
+        // conv3t_kernel: ONE N tile of 33..48 channels (the level-1 block of the 48-channel models), whole 32-channel chunks, three or six
+        // and more of them; 12 x 64 pixel tiles; stores and x loads carry 32-bit offsets inside six planes.  The choice depends on channel
+        // counts only (never on H or W): its fused variant sums the gate in another order than conv3s_kernel<.., FUSE> -- equal to <= 1 ulp,
+        // not bit for bit --, and a tile of upscale_tiled() must run the kernel the whole image runs.
+        const bool t_fuse = epi == EPI_FUSEDMIX && knobs.fuse16 && mixf && mixf->packed16t;
+        const bool use_t = knobs.t && use_s16 && !film_gamma && dtype != DT_F32 && c.packed16t && c.ntiles == 1 && persist_wgs > 0 &&
+                           (c.nchunks16t == 3 || c.nchunks16t >= 6) && ((epi == EPI_STORE) || t_fuse) &&
+                           (double)H * W * 64.0 < 4294967296.0 && 6.0 * H * W * 16.0 < 4294967296.0;
+        if (use_t) {
+            a.tiles_x = (W + 63) / 64; a.tiles_y = (H + 11) / 12;
+            a.mtiles = B * a.tiles_x * a.tiles_y;
+            pick_order(a, c, px * c.cp0 * sz);
+            a.s16 = 1; a.wpk16 = c.packed16t; a.nchunks16 = c.nchunks16t;
+            if (t_fuse) a.wmix16 = mixf->packed16t;
+            const int need = (a.grid + 7) / 8 * 8;
+            a.persist = need < persist_wgs ? need : persist_wgs;
+            const double extra_bytes = epi == EPI_FUSEDMIX ? px * c.cout * sz : 0.0;
+            ProfRec* r;
+            prof_begin(r, 2.0 * px * 9.0 * c.cin * c.cout + extra_flops, px * (c.cin + c.cout) * sz + 9.0 * c.cin * c.cout * sz + extra_bytes, 1);
+            if (r) { r->kind = 0; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.gm * 1000 + a.gn; }
+            g_last_kernel = t_fuse ? "conv3t_fused" : "conv3t";
+            check(launch_conv3t(dtype, a, s), "conv3t launch");
+            prof_end(r);
+            return;
         }
+        // padded pixels of conv3q / conv3r's 8 x 48 tiles -- and of conv3r's second geometry, 8 x 40 (five pixel fragments per wave: widths
+        // like 120 that 48 does not divide) -- against the better of the 8 x 64 / 16 x 32 tiles.  (All plain variants accumulate in the same
+        // order whatever the tile shape: bit-identical, so this choice may depend on H and W.)
+        const long long rows8 = (long long)((H + 7) / 8 * 8);
+        const long long pad48 = rows8 * ((W + 47) / 48 * 48), pad40 = rows8 * ((W + 39) / 40 * 40);
+        const long long pads = (long long)a.tiles_y * th * a.tiles_x * tw;
         // conv3r_kernel: any chunk count >= 3 of four whole planes (its halo loads carry the plane in the scalar offset, which the
         // hardware's range check does not cover); its stores carry 32-bit offsets inside 12 output planes / one D2S target image
-        const bool use_r = knobs.r && q_common && c.nchunks16 >= 3 && a.p0 % 4 == 0 &&
-                           (epi == EPI_D2S ? (double)(c.cq_p * dtype_size(dtype) / 16) * Hout * Wout * 16.0 < 4294967296.0
-                                           : 12.0 * H * W * 16.0 < 4294967296.0);
-        const bool use_q = use_r || (knobs.q && q_common && c.nchunks16 % 2 == 0);
+        const bool r_ok = knobs.r && q_common && c.nchunks16 >= 3 && a.p0 % 4 == 0 &&
+                          (epi == EPI_D2S ? (double)(c.cq_p * dtype_size(dtype) / 16) * Hout * Wout * 16.0 < 4294967296.0
+                                          : 12.0 * H * W * 16.0 < 4294967296.0);
+        const int geo = (r_ok && knobs.geo40 && pad40 < pad48) ? 1 : 0;
+        const int tw_r = geo ? 40 : 48;
+        const bool use_r = r_ok && (geo ? pad40 : pad48) <= pads;
+        const bool use_q = use_r || (knobs.q && q_common && pad48 <= pads && c.nchunks16 % 2 == 0);
         // ... and its fused variant (conv2 + AdaptiveResidualMix, C = 96): six or more chunks (one pixel fragment's gate GEMM and
         // blend per chunk), the gate weights packed in accumulator-row order, x and out within 32-bit offsets
         bool use_rf = knobs.r && knobs.fuse16 && epi == EPI_FUSEDMIX && use_s16 && dtype != DT_F32 && c.nt == 3 && c.ntiles == 1 && c.packed16 &&
@@ -762,12 +815,15 @@ struct Runner {
             ProfRec* r;
             prof_begin(r, 2.0 * px * 9.0 * c.cin * c.cout + extra_flops, px * (c.cin + c.cout) * sz + 9.0 * c.cin * c.cout * sz + px * c.cout * sz, 1);
             if (r) { r->kind = 0; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.gm * 1000 + a.gn; }
+            g_last_kernel = "conv3r_fused";
             check(launch_conv3r(dtype, a, s), "conv3r fused launch");
             prof_end(r);
             return;
         }
         if (use_q) {
-            a.tiles_x = (W + 47) / 48; a.tiles_y = (H + 7) / 8;
+            a.geo = use_r ? geo : 0;
+            const int tw_q = use_r ? tw_r : 48;  // (conv3q_kernel knows the 8 x 48 tile only)
+            a.tiles_x = (W + tw_q - 1) / tw_q; a.tiles_y = (H + 7) / 8;
             a.mtiles = B * a.tiles_x * a.tiles_y;
             pick_order(a, c, px * c.cp0 * sz);
             a.s16 = 1; a.wpk16 = c.packed16; a.nchunks16 = c.nchunks16;
@@ -776,6 +832,7 @@ struct Runner {
             ProfRec* r;
             prof_begin(r, 2.0 * px * 9.0 * c.cin * c.cout, px * (c.cin + c.cout) * sz + 9.0 * c.cin * c.cout * sz, 1);
             if (r) { r->kind = 0; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.gm * 1000 + a.gn; }
+            g_last_kernel = use_r ? (a.geo ? "conv3r_8x40" : "conv3r") : "conv3q";
             if (use_r) check(launch_conv3r(dtype, a, s), "conv3r launch");
             else check(launch_conv3q(dtype, a, s), "conv3q launch");
             prof_end(r);
@@ -812,6 +869,8 @@ struct Runner {
         ProfRec* r;
         prof_begin(r, 2.0 * px * 9.0 * c.cin * c.cout + extra_flops, px * (c.cin + c.cout) * sz + 9.0 * c.cin * c.cout * sz + extra_bytes, 1);
         if (r) { r->kind = 0; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.gm * 1000 + a.gn; }
+        g_last_kernel = mode == MODE_CONV3 ? "conv_kernel" : (a.persist > 0 ? (a.s16 ? (epi == EPI_FUSEDMIX ? "conv3s_fused" : "conv3s") : "conv3p")
+                                                                            : (epi == EPI_FUSEDMIX ? "conv3w_fused" : "conv3w"));
         check(launch_conv(dtype, mode, c.nt, a, s), "conv3x3 launch");
         prof_end(r);
     }
@@ -851,6 +910,7 @@ struct Runner {
         ProfRec* r;
         prof_begin(r, 2.0 * (double)npix * c.cin * c.cout, (double)npix * 3.0 * c.cout * sz, 0);
         if (r) { r->kind = 1; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.gm * 1000 + a.gn; }
+        g_last_kernel = mix16b ? "mix16b" : (mix16 ? "mix16" : "conv_kernel_mix");
         if (mix16b) check(launch_mix16b(dtype, a, s, mix16b_wgs), "mix16b launch");
         else if (mix16) check(launch_mix16(dtype, a, s), "mix16 launch");
         else check(launch_conv(dtype, MODE_GEMM1, c.nt, a, s), "mix launch");
@@ -1057,13 +1117,14 @@ extern "C" int mz_op_conv(int dtype, int kind, const void* in0, const void* in1,
         case 3: plan_conv(c, dtype, MODE_GEMM1, cout, 2 * cout, 1, 1, OUT_PLAIN, SRC_CONCAT, cout, cout); break;
         default: return fail(MZ_ERR_INVALID_ARGUMENT, "bad op kind %d", kind);
     }
-    TempBuf zero, packed, packed16, packed16r;
+    TempBuf zero, packed, packed16, packed16r, packed16t;
     HIPCHK(hipMalloc(&zero.p, 4096));
     HIPCHK(hipMemsetAsync(zero.p, 0, 4096, s));
     rc = pack_conv(c, dtype, w_dev_f32, s);
     packed.p = c.packed;
     packed16.p = c.packed16;
     packed16r.p = c.packed16r;   // kind 3, C = 192: the second packing of the gate weights (mix16b_kernel)
+    packed16t.p = c.packed16t;   // kind 0, one N tile of 33..48 channels: conv3t_kernel's packing
     if (rc) return rc;
     // a throw-away handle carries the zero page / staging choice for Runner
     mz_handle fake;
@@ -1111,15 +1172,16 @@ extern "C" int mz_op_conv_mix(int dtype, const void* hid, const void* x, const f
     if (dtype != DT_F32) {
         f.nchunks16 = (f.cp0 + 31) / 32 + f.nt;
         f.packed16_sz = packed_bytes(1, 2 * f.nt, 1, f.nchunks16);
+        if (f.cp0 == 48) f.packed16t_sz = packed_bytes(1, 3, 1, 3);
     }
-    TempBuf zero, p0, p1, p2, p3, p4;
+    TempBuf zero, p0, p1, p2, p3, p4, p5, p6;
     HIPCHK(hipMalloc(&zero.p, 4096));
     HIPCHK(hipMemsetAsync(zero.p, 0, 4096, s));
     rc = pack_conv(c2, dtype, w2_dev_f32, s);
-    p0.p = c2.packed; p1.p = c2.packed16;
+    p0.p = c2.packed; p1.p = c2.packed16; p5.p = c2.packed16t;
     if (rc) return rc;
     rc = pack_conv(f, dtype, wmix_dev_f32, s);
-    p2.p = f.packed; p3.p = f.packed16; p4.p = f.packed16r;
+    p2.p = f.packed; p3.p = f.packed16; p4.p = f.packed16r; p6.p = f.packed16t;
     if (rc) return rc;
     mz_handle fake;
     fake.zero_page = zero.p;
@@ -1144,12 +1206,13 @@ extern "C" int mz_op_conv_film(int dtype, const void* in0, const float* w_dev_f3
     hipStream_t s = (hipStream_t)hip_stream;
     ConvW c;
     plan_conv(c, dtype, MODE_CONV3, cout, cin, 3, 3, OUT_PLAIN, SRC_PLAIN, 0, 0);
-    TempBuf zero, packed, packed16, gpad, bpad;
+    TempBuf zero, packed, packed16, packed16t, gpad, bpad;
     HIPCHK(hipMalloc(&zero.p, 4096));
     HIPCHK(hipMemsetAsync(zero.p, 0, 4096, s));
     rc = pack_conv(c, dtype, w_dev_f32, s);
     packed.p = c.packed;
     packed16.p = c.packed16;
+    packed16t.p = c.packed16t;
     if (rc) return rc;
     // gamma / beta [B][cout] -> [B][padded cout], pad channels zero
     const int cp = pad16(cout);
@@ -1214,6 +1277,7 @@ extern "C" int mz_op_final(int dtype, const void* feat, const void* img, const f
 // introspection
 // ------------------------------------------------------------------------------------------------
 extern "C" const char* mz_last_error(void) { return g_err; }
+extern "C" const char* mz_debug_last_kernel(void) { return g_last_kernel; }
 extern "C" const char* mz_version(void) { return "mewzoom_hip 0.1 (gfx950)"; }
 
 extern "C" double mz_flops_per_image(const mz_handle* h, int H, int W) {

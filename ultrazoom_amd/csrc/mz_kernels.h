@@ -73,6 +73,7 @@ struct ConvArgs {
     int s16;           // persistent launches of 16-bit types: use the 16x16x32-MFMA kernel (needs wpk16)
     const void* wpk16; // weights packed for it: [ntile][32-channel chunk][tap][2*nt][64 lanes][16 B]
     int nchunks16;     // 32-channel chunks
+    int geo;           // conv3r_kernel: pixel-tile geometry, 0 = 8 x 48 (six pixel fragments per wave), 1 = 8 x 40 (five)
     const void* wmix16; // EPI_FUSEDMIX on the 16x16x32 kernel: gate weights packed [2*nt K-steps][2*nt][64 lanes][16 B]
     const float* film_gamma;  // EPI_STORE on conv3s_kernel only: per-image per-channel affine gamma * y + beta ahead of the SiLU
     const float* film_beta;   //   (float [B][cp_out], pad channels zero); nullptr = off.  No reference counterpart.
@@ -100,6 +101,10 @@ hipError_t init_conv3q();
 // (32-bit store offsets: 12 planes of the output, resp. one whole D2S target image, must stay below 4 GiB); EPI_FUSEDMIX: >= 6
 // chunks, a.wmix16 = gate weights packed with PackArgs::frag16 = 2, a.in1 / a.p1 = the block input.
 hipError_t launch_conv3r(int dtype, const ConvArgs& a, hipStream_t s);
+// conv3t_kernel (mz_conv3t.h): conv3r's role-alternating structure for ONE N tile of <= 48 channels (three 16-channel fragments x twelve
+// pixel fragments per wave, 12 x 64 pixel tiles).  a.wpk16 = weights packed with PackArgs::nfr = 3; a.nchunks16 = 3 or >= 6; EPI_STORE
+// (plain / SiLU) or EPI_FUSEDMIX (a.wmix16 = gate weights packed with PackArgs::frag16 = 4, a.in1 / a.p1 = the block input).
+hipError_t launch_conv3t(int dtype, const ConvArgs& a, hipStream_t s);
 
 // ---- weight packing ---------------------------------------------------------------------------
 enum OutMap : int { OUT_PLAIN = 0, OUT_D2S = 1, OUT_FINAL = 2 };
@@ -116,7 +121,9 @@ struct PackArgs {
     int frag16;        // 1: fragments of the 16x16x32 MFMA (16 channels x 32 K; 16-bit types); nchunks counts 32-channel chunks.  2 (SRC_MIXF): ... with
                        // the x half of the gate weights in accumulator-row order as well (conv3r_kernel's fused variant)
                        // 3 (SRC_CONCAT, nt = 6): mix16b_kernel's row and K-step order
+                       // 4 (SRC_MIXF, nfr = 3, nchunks = 3): conv3t_kernel's gate: K step s = fragments 2 s, 2 s + 1 of [x0 x1 x2 z0 z1 z2]
     int c0, cp0, c1;   // CONCAT: real/padded channels of in0, real channels of in1;  PLAIN/CRUSH: c0 = cin, cp0 = padded cin
+    int nfr;           // frag16 packings: 16-channel fragments per tap and N tile; 0 = 2 * nt (conv3t_kernel: 3)
 };
 size_t packed_bytes(int taps, int nt, int ntiles, int nchunks);
 size_t conv16_lds_bytes(int mode, int nt, bool fuse);

@@ -2154,7 +2154,7 @@ template <class TT> __global__ void pack_kernel(const PackArgs a, long long tota
     long long t = idx;
     const int e = (int)(t % EPL); t /= EPL;
     const int lane = (int)(t % 64); t /= 64;
-    const int nfr = a.frag16 ? 2 * a.nt : a.nt;  // fragments per tap: 16-channel (16x16x32 MFMA) or 32-channel ones
+    const int nfr = a.frag16 ? (a.nfr ? a.nfr : 2 * a.nt) : a.nt;  // fragments per tap: 16-channel (16x16x32 MFMA) or 32-channel ones
     const int nt = (int)(t % nfr); t /= nfr;
     const int tap = (int)(t % a.taps); t /= a.taps;
     const int kc = (int)(t % a.nchunks); t /= a.nchunks;
@@ -2206,6 +2206,15 @@ template <class TT> __global__ void pack_kernel(const PackArgs a, long long tota
         const int k = ks * ckk + kin;
         if (k < a.cp0) ci = k < a.c0 ? k : -1;
         else ci = (k - a.cp0) < a.c1 ? a.c0 + (k - a.cp0) : -1;
+    } else if (a.in_map == SRC_MIXF && a.frag16 == 4) {
+        // conv3t_kernel's gate (C <= 48: three 16-channel fragments of x, three of z): K step kc = fragments 2 kc and 2 kc + 1 of
+        // [x0 x1 x2 z0 z1 z2], the K elements of lane group g in accumulator-row order: e < 4 -> the first fragment's channels 4 g + e,
+        // e >= 4 -> the second's
+        const int g = lane >> 4;
+        const int fr = 2 * kc + (e < 4 ? 0 : 1);
+        const int ch = 16 * (fr % 3) + 4 * g + (e & 3);
+        if (fr < 3) ci = ch < a.c0 ? ch : -1;
+        else ci = ch < a.c1 ? a.c0 + ch : -1;
     } else if (a.in_map == SRC_MIXF && a.frag16) {
         // fused gate for the 16x16x32 kernel: K-steps [0, ncx) = x channels in natural order (32 per step); then one
         // K-step per PAIR of 16-channel accumulator fragments of z, K elements in the order the accumulator quads of
@@ -2257,7 +2266,7 @@ size_t packed_bytes(int taps, int nt, int ntiles, int nchunks) {
 
 hipError_t launch_pack(const PackArgs& a, hipStream_t s) {
     const int sz = dtype_size(a.dtype);
-    const long long total = (long long)packed_bytes(a.taps, a.frag16 ? 2 * a.nt : a.nt, a.ntiles, a.nchunks) / sz;
+    const long long total = (long long)packed_bytes(a.taps, a.frag16 ? (a.nfr ? a.nfr : 2 * a.nt) : a.nt, a.ntiles, a.nchunks) / sz;
     const int blocks = (int)((total + 255) / 256);
     switch (a.dtype) {
         case DT_F32: hipLaunchKernelGGL(pack_kernel<TF32>, dim3(blocks), dim3(256), 0, s, a, total); break;
