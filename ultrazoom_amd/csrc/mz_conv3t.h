@@ -52,7 +52,13 @@ constexpr int CHUNK_PIECES = 9 * NF;            // 27 KB of weights per 32-chann
 constexpr int SEG_PIECES = 3 * NF;              // three taps
 constexpr int MIX_BASE = B_BASE + CHUNK_PIECES * 1024;
 constexpr int MIX_PIECES = 3 * NF;              // gate weights: three K steps x three fragments
-constexpr int lds_bytes(bool fuse) { return fuse ? MIX_BASE + MIX_PIECES * 1024 : MIX_BASE; }
+// 1 KB behind everything else: the target of DUMMY halo pieces.  Every wave issues the same NUMBER of halo pieces (wave 3, whose share of
+// a plane is one piece short, issues a piece nobody reads), so that a chunk's first step can close with a COUNTED vmcnt wait that leaves
+// the halo image -- issued LAST in the step, needed two steps later -- in flight: it comes from HBM, and waiting for it at the end of the
+// step it was requested in cost the helper 1 - 2 k cycles per chunk (tools/stamp_probe_t.py).
+constexpr int dump_base(bool fuse) { return fuse ? MIX_BASE + MIX_PIECES * 1024 : MIX_BASE; }
+constexpr int lds_bytes(bool fuse) { return dump_base(fuse) + 1024; }
+constexpr int HALO_PIECES = 16;                 // halo pieces a wave issues per chunk (four planes x four, dummies included)
 static_assert(lds_bytes(true) <= 160 * 1024, "LDS of a CU");
 static_assert(NPF == RPW * FPR && NPF == 2 * GPF, "two groups of six pixel fragments per tap");
 
@@ -192,6 +198,9 @@ __global__ __launch_bounds__(512) void conv3t_kernel(const ConvArgs a) {
     f32x4 acc[NPF][NF];
     Frag f;
     int done_mt = 0;
+    RS_DECL;  // diagnostic builds (-DMZ_DIAG, mz_diag.h; tools/stamp_probe_t.py): counters 0 / 1 = K-loop cycles / tiles, 2 = final epilogue;
+              // step class c = (chunk's first step ? 0 : 1) + (epilogue work ? 2 : 0): 4 c + 4 .. + 7 = request + DMA issue / epilogue /
+              // vmcnt wait / barrier, 24 + c = steps of the class; 3 = phase start (offsets, epilogue setup)
     const long long plane_in = (long long)a.H * a.W * 16;
     const char* const wbase = (const char*)a.wpk16;  // one N tile: [chunk][tap][fragment][64 lanes][16 B]
 
@@ -226,19 +235,27 @@ __global__ __launch_bounds__(512) void conv3t_kernel(const ConvArgs a) {
     };
     auto halo_piece = [&](auto pl_tag, auto i_tag, const __amdgpu_buffer_rsrc_t rsrc, char* dst) __attribute__((always_inline)) {
         constexpr int pl = decltype(pl_tag)::value, i = decltype(i_tag)::value;
-        if (i < 3 || wq < PLANE_PIECES - 12)
+        if constexpr (i < 3) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + (pl * PLANE_PIECES + wq + 4 * i) * 1024), 16,
                                                      (int)hoff[i], (int)((uint32_t)pl * (uint32_t)plane_in), 0, 0);
+        } else {
+            // in-plane piece wq + 12 exists for wq < 3; wave 3 issues a dummy in its place (all lanes out of range: no memory traffic, zeros
+            // into the dump area), so that every wave issues four pieces per plane
+            const bool real = wq < PLANE_PIECES - 12;
+            char* const d = real ? dst + (pl * PLANE_PIECES + wq + 12) * 1024 : smem + dump_base(FUSE);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)d, 16, real ? (int)hoff[3] : -1,
+                                                     (int)((uint32_t)pl * (uint32_t)plane_in), 0, 0);
+        }
     };
-    auto halo_image = [&](int kc, int slot) __attribute__((always_inline)) {
+    // planes [2 half, 2 half + 2) of chunk kc's image -> halo slot `slot`: eight pieces per wave
+    auto halo_half = [&](auto half_tag, int kc, int slot) __attribute__((always_inline)) {
+        constexpr int P = 2 * decltype(half_tag)::value;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(img_l + 4LL * kc * plane_in), 0, (int)(uint32_t)(4 * plane_in), 0x00020000);
         uint32_t h_off = (uint32_t)slot * (uint32_t)A_SLOT;
         asm volatile("" : "+s"(h_off));  // (opaque: no piece addresses kept alive -- and spilled -- from chunk to chunk)
         char* const dst = smem + h_off;
-        halo_piece(ic<0>{}, ic<0>{}, rsrc, dst); halo_piece(ic<0>{}, ic<1>{}, rsrc, dst); halo_piece(ic<0>{}, ic<2>{}, rsrc, dst); halo_piece(ic<0>{}, ic<3>{}, rsrc, dst);
-        halo_piece(ic<1>{}, ic<0>{}, rsrc, dst); halo_piece(ic<1>{}, ic<1>{}, rsrc, dst); halo_piece(ic<1>{}, ic<2>{}, rsrc, dst); halo_piece(ic<1>{}, ic<3>{}, rsrc, dst);
-        halo_piece(ic<2>{}, ic<0>{}, rsrc, dst); halo_piece(ic<2>{}, ic<1>{}, rsrc, dst); halo_piece(ic<2>{}, ic<2>{}, rsrc, dst); halo_piece(ic<2>{}, ic<3>{}, rsrc, dst);
-        halo_piece(ic<3>{}, ic<0>{}, rsrc, dst); halo_piece(ic<3>{}, ic<1>{}, rsrc, dst); halo_piece(ic<3>{}, ic<2>{}, rsrc, dst); halo_piece(ic<3>{}, ic<3>{}, rsrc, dst);
+        halo_piece(ic<P>{}, ic<0>{}, rsrc, dst); halo_piece(ic<P>{}, ic<1>{}, rsrc, dst); halo_piece(ic<P>{}, ic<2>{}, rsrc, dst); halo_piece(ic<P>{}, ic<3>{}, rsrc, dst);
+        halo_piece(ic<P + 1>{}, ic<0>{}, rsrc, dst); halo_piece(ic<P + 1>{}, ic<1>{}, rsrc, dst); halo_piece(ic<P + 1>{}, ic<2>{}, rsrc, dst); halo_piece(ic<P + 1>{}, ic<3>{}, rsrc, dst);
     };
     // weight segment sgm (three taps, nine pieces) of chunk kc -> its fixed place in LDS; wave wq issues pieces wq, wq + 4, wq + 8 (< 9)
     auto weight_segment = [&](int kc, int sgm) __attribute__((always_inline)) {
@@ -251,7 +268,8 @@ __global__ __launch_bounds__(512) void conv3t_kernel(const ConvArgs a) {
     };
 
     // ---- epilogue of the finished tile `done_mt` ----
-    __amdgpu_buffer_rsrc_t orsrc, xrsrc;
+    __amdgpu_buffer_rsrc_t orsrc;
+    u32x4 xrsrc = {0u, 0u, 0u, 0u};  // FUSE: buffer descriptor of the block input x (in1) of the finished tile's image, for inline-asm loads
     uint32_t e_pix = 0, eoff1 = 0, eoff2 = 0, x_lane = 0;
     int e_c = 0, e_c2 = 0, e_y = 0;
     auto epi_setup = [&]() __attribute__((always_inline)) {
@@ -269,7 +287,11 @@ __global__ __launch_bounds__(512) void conv3t_kernel(const ConvArgs a) {
         eoff2 = (uint32_t)(4 + (g >> 1)) * (uint32_t)plane_o + (uint32_t)(g & 1) * 256u;  // fragment 2: plane 4 + (g >> 1), 16 pixels on for odd lane rows
         if constexpr (FUSE) {
             // x in ACCUMULATOR layout: channels 16 nf + 4 g .. + 3 of the lane's pixel = 8 bytes (g & 1) of plane 2 nf + (g >> 1)
-            xrsrc = __builtin_amdgcn_make_buffer_rsrc((char*)a.in1 + (long long)d_b * a.p1 * plane_o, 0, (int)(uint32_t)(a.p1 * plane_o), 0x00020000);
+            const unsigned long long xb = (unsigned long long)(uintptr_t)((const char*)a.in1 + (long long)d_b * a.p1 * plane_o);
+            xrsrc[0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xb);
+            xrsrc[1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((xb >> 32) & 0xffffu));
+            xrsrc[2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a.p1 * plane_o));  // bytes: loads beyond them return zeros
+            xrsrc[3] = 0x00020000u;
             x_lane = (uint32_t)(g >> 1) * (uint32_t)plane_o + (uint32_t)(g & 1) * 8u;
         }
     };
@@ -278,7 +300,8 @@ __global__ __launch_bounds__(512) void conv3t_kernel(const ConvArgs a) {
 
     // FUSE state: x of up to four pixel fragments (ring by pf & 3: requested one step ahead), z of the unit in work; both as packed
     // pairs in accumulator layout: [channel fragment][2 words]
-    uint32_t f_x[4][NF][2];
+    typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
+    u32x2_ f_x[4][NF];  // (64-bit elements: the inline-asm loads below write them in place)
     uint32_t f_z[NF][2];
     uint32_t held[2];  // fragment-2 words of an even pixel fragment, waiting for its odd neighbour
     auto fuse_x = [&](auto pf_tag) __attribute__((always_inline)) {  // request x of pixel fragment pf
@@ -289,9 +312,23 @@ __global__ __launch_bounds__(512) void conv3t_kernel(const ConvArgs a) {
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
             const uint32_t o = inside ? off + (uint32_t)(2 * nf) * (uint32_t)plane_o : 0xffffffffu;  // planes >= p1 fall out of range: zeros
-            const auto v = __builtin_amdgcn_raw_buffer_load_b64(xrsrc, (int)o, 0, 0);
-            f_x[pf & 3][nf][0] = v[0];
-            f_x[pf & 3][nf][1] = v[1];
+            // Inline asm: hipcc's waitcnt pass must not see these loads.  It would wait for them in front of their first use with what it
+            // can count -- which is vmcnt(0) once conditional DMA pieces lie in between, i.e. for the halo image a step's closing wait
+            // deliberately leaves in flight.  The request is older than that step's DMA, so the closing wait of the step it is issued in
+            // covers it; x_landed() marks the spot from which the values may be used.
+            // The destination is the ring element itself: a copy behind the asm would read the register before the data arrives.
+            u32x2_& dst = f_x[pf & 3][nf];
+            const u32x4& xr = xrsrc;  // (named: an asm operand alone does not make a generic lambda capture it)
+            asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(o), "s"(xr) : "memory");
+        }
+    };
+    // x of pixel fragment pf, requested by fuse_x() at least one closing wait ago: from here on the registers hold it
+    auto x_landed = [&](auto pf_tag) __attribute__((always_inline)) {
+        constexpr int pf = decltype(pf_tag)::value;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+            u32x2_& r = f_x[pf & 3][nf];  // (named first: an asm operand alone does not make a generic lambda capture the array)
+            asm volatile("" : "+v"(r));
         }
     };
     // values of an entry, packed: out of place (accumulator elements are read where they lie), activation / blend as inline-asm pairs
@@ -440,30 +477,36 @@ __global__ __launch_bounds__(512) void conv3t_kernel(const ConvArgs a) {
         constexpr int XS = decltype(xs_tag)::value, XN = decltype(xn_tag)::value, sg = decltype(sg_tag)::value;
         constexpr bool last = decltype(last_tag)::value != 0;
         static_assert(EN <= 2 && XN <= 2, "at most two units / entries per step");
-        // VMEM instructions issued BEHIND this step's DMA: the stores
-        constexpr int VM_AFTER = WK == 1 ? EN : (WK == 2 ? (EN > 0 ? 1 + (ES & 1) : 0) + (EN > 1 ? 1 + ((ES + 1) & 1) : 0) : 0);
-        if constexpr (FUSE && WK == 2) {
-            // x of this step's units was requested a step ago and is covered by that step's closing wait; naming the registers here
-            // makes hipcc place its own (conservative) wait BEFORE this step's DMA issue, not behind it
-#pragma unroll
-            for (int u = 0; u < EN; ++u)
-#pragma unroll
-                for (int nf = 0; nf < NF; ++nf) asm volatile("" ::"v"(f_x[(ES + u) & 3][nf][0]), "v"(f_x[(ES + u) & 3][nf][1]));
+        // VMEM instructions this step issues BEHIND its weight pieces: in a chunk's first step the halo image of the next chunk (the same
+        // count in every wave), then the stores.  The step closes with vmcnt(that many) (loads, stores and LDS-DMA retire in issue order):
+        // the weight segment has landed -- the compute waves prefetch out of it before the next barrier --, the halo image may stay in
+        // flight: the closing wait of the chunk's SECOND step covers it, a step before the compute waves first read it.
+        constexpr int VM_AFTER = (sg == 0 ? HALO_PIECES : 0) +
+                                 (WK == 1 ? EN : (WK == 2 ? (EN > 0 ? 1 + (ES & 1) : 0) + (EN > 1 ? 1 + ((ES + 1) & 1) : 0) : 0));
+        static_assert(VM_AFTER < 64, "vmcnt is a 6-bit counter");
+        [[maybe_unused]] constexpr int rs_c = (sg == 0 ? 0 : 1) + (EN > 0 ? 2 : 0);
+        RS_BEGIN();
+        if constexpr (FUSE && WK == 2) {  // x of this step's units: requested a step ago, covered by that step's closing wait
+            if constexpr (EN > 0) x_landed(ic<ES>{});
+            if constexpr (EN > 1) x_landed(ic<(EN > 1 ? ES + 1 : ES)>{});
         }
         if constexpr (FUSE && XN > 0) {
             fuse_x(ic<XS>{});
             if constexpr (XN > 1) fuse_x(ic<(XN > 1 ? XS + 1 : XS)>{});
             __builtin_amdgcn_sched_barrier(0);
         }
-        // ---- this step's DMA: in a chunk's first step the next chunk's halo image (first: its data comes from HBM and takes longest),
-        //      then weight segment (sg + 2) % 3 -- of this chunk in the first step, of the next chunk otherwise ----
-        if constexpr (sg == 0) {
-            if (!last || okB) halo_image(last ? 0 : k + 1, us ^ 1);
-        }
+        // ---- this step's DMA: weight segment (sg + 2) % 3 -- of this chunk in the first step, of the next chunk otherwise --, then, in a
+        //      chunk's first step, the next chunk's halo image (of tB's first chunk in a tile's last chunk; without a tB the offsets still
+        //      describe tA: a harmless re-load into the free slot keeps the piece count) ----
         if constexpr (sg == 0) weight_segment(k, 2);
         else weight_segment(last ? 0 : k + 1, sg - 1);
+        if constexpr (sg == 0) {
+            halo_half(ic<0>{}, last ? 0 : k + 1, us ^ 1);
+            halo_half(ic<1>{}, last ? 0 : k + 1, us ^ 1);
+        }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("" ::: "memory");
+        RS_LAP(4 * rs_c + 4);
         // ---- this step's share of the finished tile's epilogue, behind the DMA issue ----
         if constexpr (WK == 1) {
             if constexpr (EN > 0) plain_entry(ic<ES>{});
@@ -488,8 +531,13 @@ __global__ __launch_bounds__(512) void conv3t_kernel(const ConvArgs a) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        wait_vmcnt<VM_AFTER>();  // the DMA has landed once at most this step's stores (issued behind it) are outstanding
+        RS_FENCE();
+        RS_LAP(4 * rs_c + 5);
+        wait_vmcnt<VM_AFTER>();
+        RS_LAP(4 * rs_c + 6);
         __builtin_amdgcn_s_barrier();
+        RS_LAP(4 * rs_c + 7);
+        RS_COUNT(24 + rs_c);
         if constexpr (sg == 2) us ^= 1;  // the chunk is complete
     };
     // chunk K of a tile's epilogue schedule (K compile-time, k = its run-time twin), SHORT: the tile has three chunks
@@ -519,9 +567,12 @@ __global__ __launch_bounds__(512) void conv3t_kernel(const ConvArgs a) {
     auto loader_phase = [&](auto epi_tag) __attribute__((always_inline)) {
         constexpr bool DO_EPI = decltype(epi_tag)::value != 0;
         okB = b_pos < cnt;
+        RS_BEGIN();
         set_load_tile(a_mt);
         if constexpr (DO_EPI) {
             epi_setup();
+            RS_FENCE();
+            RS_LAP(3);
             if (nchunks == 3) {
                 epi_chunk(ic<1>{}, ic<0>{}, ic<0>{}, 0);
                 epi_chunk(ic<1>{}, ic<1>{}, ic<0>{}, 1);
@@ -553,6 +604,7 @@ __global__ __launch_bounds__(512) void conv3t_kernel(const ConvArgs a) {
         const uint32_t a_lane = lds_base + g * A_PLANE + ((RPW * wq) * ROWW + c) * 16;
         uint32_t a_cur = a_lane + us * A_SLOT, a_nxt = a_lane + (us ^ 1) * A_SLOT;
         const uint32_t b_lane = lds_base + B_BASE + lane_ * 16;
+        RS_BEGIN();
         for (int kc = 0; kc < nchunks; ++kc) {
             const bool first = !FUSE && kc == 0;  // (the fused variant clears its accumulators in the helper role: see there)
             groups<TT, 0, 6>(acc, f, a_cur, a_nxt, b_lane, first);
@@ -565,15 +617,26 @@ __global__ __launch_bounds__(512) void conv3t_kernel(const ConvArgs a) {
         }
         // (the last group requested fragments of a "next chunk" nobody computes here: its closing wait was lgkmcnt(0), they have landed;
         // the registers are dead from here on)
+        RS_LAP(0);
+        RS_COUNT(1);
         us ^= nchunks & 1;
         done_mt = a_mt;
     };
     auto final_epilogue = [&]() __attribute__((always_inline)) {
         epi_setup();
         if constexpr (FUSE) {
-            fuse_x(ic<0>{}); fuse_unit(ic<0>{}); fuse_x(ic<1>{}); fuse_unit(ic<1>{}); fuse_x(ic<2>{}); fuse_unit(ic<2>{}); fuse_x(ic<3>{}); fuse_unit(ic<3>{});
-            fuse_x(ic<4>{}); fuse_unit(ic<4>{}); fuse_x(ic<5>{}); fuse_unit(ic<5>{}); fuse_x(ic<6>{}); fuse_unit(ic<6>{}); fuse_x(ic<7>{}); fuse_unit(ic<7>{});
-            fuse_x(ic<8>{}); fuse_unit(ic<8>{}); fuse_x(ic<9>{}); fuse_unit(ic<9>{}); fuse_x(ic<10>{}); fuse_unit(ic<10>{}); fuse_x(ic<11>{}); fuse_unit(ic<11>{});
+            // (no partner, no DMA: x one unit ahead, an explicit wait for it -- all but the next unit's three loads and this unit's stores --)
+            auto unit = [&](auto pf_tag) __attribute__((always_inline)) {
+                constexpr int pf = decltype(pf_tag)::value;
+                if constexpr (pf + 1 < NPF) fuse_x(ic<(pf + 1 < NPF ? pf + 1 : 0)>{});
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (pf + 1 < NPF) wait_vmcnt<NF>(); else wait_vmcnt<0>();
+                x_landed(pf_tag);
+                fuse_unit(pf_tag);
+            };
+            fuse_x(ic<0>{});
+            unit(ic<0>{}); unit(ic<1>{}); unit(ic<2>{}); unit(ic<3>{}); unit(ic<4>{}); unit(ic<5>{});
+            unit(ic<6>{}); unit(ic<7>{}); unit(ic<8>{}); unit(ic<9>{}); unit(ic<10>{}); unit(ic<11>{});
         } else {
             plain_entry(ic<0>{}); plain_entry(ic<1>{}); plain_entry(ic<2>{}); plain_entry(ic<3>{}); plain_entry(ic<4>{}); plain_entry(ic<5>{});
             plain_entry(ic<6>{}); plain_entry(ic<7>{}); plain_entry(ic<8>{}); plain_entry(ic<9>{}); plain_entry(ic<10>{}); plain_entry(ic<11>{});
@@ -585,7 +648,8 @@ __global__ __launch_bounds__(512) void conv3t_kernel(const ConvArgs a) {
     if (team == 1) {
         // prologue: chunk 0 of the first tile (halo image + its first two weight segments), published by B_0
         set_load_tile(a_mt);
-        halo_image(0, 0);
+        halo_half(ic<0>{}, 0, 0);
+        halo_half(ic<1>{}, 0, 0);
         weight_segment(0, 0);
         weight_segment(0, 1);
         if constexpr (FUSE) {  // the gate weights, resident for the whole launch: nine pieces
@@ -598,7 +662,7 @@ __global__ __launch_bounds__(512) void conv3t_kernel(const ConvArgs a) {
         __builtin_amdgcn_s_barrier();  // B_0
         loader_phase(ic<0>{});  // (its last step clears the fused variant's accumulators and primes the fragment stream)
         advance();
-        if (a_pos >= cnt) return;
+        if (a_pos >= cnt) { RS_DUMP(); return; }
     } else {
         __builtin_amdgcn_s_barrier();  // B_0
         if constexpr (FUSE) {
@@ -613,12 +677,15 @@ __global__ __launch_bounds__(512) void conv3t_kernel(const ConvArgs a) {
         compute_phase();
         advance();
         if (a_pos >= cnt) {
+            RS_BEGIN();
             final_epilogue();
+            RS_LAP(2);
+            RS_DUMP();
             return;
         }
         loader_phase(ic<1>{});
         advance();
-        if (a_pos >= cnt) return;
+        if (a_pos >= cnt) { RS_DUMP(); return; }
     }
 }
 
