@@ -27,7 +27,7 @@ else:
 sd = synth_state_dict(parameter_shapes(cfg), seed=1234)
 models = {}
 for name, env in VARIANTS.items():
-    for k in ("MZ_Q", "MZ_NO_Q", "MZ_NO_R", "MZ_NO_T", "MZ_NO_GEO40", "MZ_NO_BLK4", "MZ_KPAD_PCT"):
+    for k in [k for k in os.environ if k.startswith("MZ_") and not k.startswith("MZ_DEBUG")]:  # every kernel-selection knob
         os.environ.pop(k, None)
     os.environ.update(env)
     m = MewZoom(**cfg); m.load_state_dict(sd); m = m.to("cuda", torch.bfloat16).eval()
