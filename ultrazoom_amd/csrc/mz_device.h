@@ -298,9 +298,11 @@ __device__ __forceinline__ void tile_rc_s(const ConvArgs& a, int trem, int& tyi,
 // anything between them.  tools/asm_store_hazard.py re-checks the listings of every build (tests/test_kernel_resources.py).
 __device__ __forceinline__ void store16_soff(const u32x4& v, const __amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
     __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voffset, soffset, 0);
+#ifndef MZ_HAZARD_DEMO  // (-DMZ_HAZARD_DEMO: the round-3 bug on purpose, for tools/debug/mix192_probe.py's "before" record)
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 1");
     __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
