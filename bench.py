@@ -89,7 +89,7 @@ def host_cores() -> int:
     return max(1, n)
 
 
-TRAFFIC_PROFILE = REPO / "profiles" / "r03_pmc_traffic_conv3x3.json"
+TRAFFIC_PROFILE = REPO / "profiles" / "r04_pmc_traffic_conv3x3.json"
 
 
 def kernel_source_sha256() -> str:
