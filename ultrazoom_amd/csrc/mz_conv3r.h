@@ -35,10 +35,14 @@
 //   * the lane index behind a step's weight pieces is worked out once per step, the piece index goes into the scalar base.
 //
 // NSEG = weight segments (= barriers) per 32-channel chunk: 2 (14 + 13 groups, 3 x 28 KB weight slots, as conv3q) or 3
-// (9 + 9 + 9 groups = tap rows, 3 x 18 KB slots).  NSEG = 3 leaves 42 KB of LDS free: the fused variant (EPI_FUSEDMIX)
-// keeps the 36 KB of AdaptiveResidualMix gate weights resident there for the whole launch.
+// (9 + 9 + 9 groups = tap rows, 3 x 18 KB slots).  Shipped: 3 everywhere (mz_conv3r.hip).  With three steps per chunk the compute
+// role first touches the NEXT halo image in the chunk's third step, so the helper issues that image BEHIND the first step's weight
+// pieces and its closing wait leaves the eight pieces in flight (HALO_LATE in loader_step()): the lines have two steps to come out of
+// HBM instead of one, and the helper of the 3- and 6-chunk layers no longer sits in front of vmcnt (96 -> 192 -6 %, 192 -> 384 -3.5 %,
+// deep layers unchanged; EXPERIMENTS.md R4.9).  NSEG = 3 also leaves 42 KB of LDS free: the fused variant (EPI_FUSEDMIX) keeps the
+// 36 KB of AdaptiveResidualMix gate weights resident there for the whole launch.
 //
-// LDS map: [halo 0 | halo 1] 2 x 32 KB + 3 weight slots (+ NSEG = 3, fused: 36 KB gate weights).
+// LDS map: [halo 0 | halo 1] 2 x 32 KB + 3 weight slots (+ fused: 36 KB gate weights).
 #pragma once
 #include <type_traits>
 #include "mz_device.h"
@@ -198,11 +202,6 @@ __device__ __forceinline__ void groups(f32x4 (&acc)[Geo<GEO>::NPF][NF], Frag<Geo
     }
 }
 
-// what the epilogue of a finished tile needs to know about it
-struct Done {
-    int mt, nt;
-};
-
 // gate GEMM of the fused mix (as conv3s_kernel<.., FUSE>): 2 NT K-steps of NF weight fragments, walked in half steps of NT
 // fragments; the next half step's fragments are requested before the current one's MFMAs are issued
 template <int H, int I> __device__ __forceinline__ void gate_reads(u32x4 (&wv)[NT], uint32_t addr) {
@@ -322,34 +321,37 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     const int nchunks = a.nchunks16;       // 32-channel chunks, >= 3 (the host guards)
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
-    // ---- tile walk (as conv3s_kernel: an XCD's contiguous id range, strided by the workgroups of that XCD) ----
+    // ---- tile walk: the host lists the launch's tiles in walk order (mz_host.cpp: tile_table(); a.grid entries of eight bytes, the
+    // group walk of mz_device.h with the padding ids dropped).  XCD x owns the x-th eighth of the list, its workgroups stride through it.
+    // Tile coordinates come out of the table with ONE scalar load per tile, requested two tiles ahead at the start of a helper phase:
+    // the divisions of tile_of_s() / tile_rc_s() (three chains of ~50 scalar instructions per phase, at ~5 cycles each in the role
+    // that is the critical path of the short tiles) are gone from the kernel. ----
     const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3, step = gridDim.x >> 3;
     const int q = a.grid >> 3, rem = a.grid & 7;
     const int cnt = q + (xcd < rem ? 1 : 0);
     const int base = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
-    auto seek = [&](int i, int& mt, int& nt) __attribute__((always_inline)) {
-        while (i < cnt && !tile_of_s(a, base + i, mt, nt)) i += step;
-        return i;
+    if (pos >= cnt) return;  // uniform over the workgroup
+    // (constant address space: a wave-uniform load from it is an s_load whose wait hipcc places itself; the table is padded behind its
+    // last entry, so entries past an XCD's range may be loaded -- and are never used: a_pos + .. < cnt decides)
+    typedef uint32_t TabE __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(4))) TabE* TabPtr;
+    const TabPtr tab = (TabPtr)(uintptr_t)a.tile_tab + base;
+    struct TileE { uint32_t yx, bn; };  // y0 | x0 << 16, image | N tile << 16
+    auto tile_at = [&](int i) __attribute__((always_inline)) {
+        const TabE e = tab[i];
+        return TileE{e[0], e[1]};
     };
-    // tA = the tile the workgroup is computing (or about to), tB = the one after it
-    int a_pos, a_mt = 0, a_nt = 0, b_pos, b_mt = 0, b_nt = 0;
-    a_pos = seek(pos, a_mt, a_nt);
-    if (a_pos >= cnt) return;  // uniform over the workgroup
-    b_pos = seek(a_pos + step, b_mt, b_nt);
-    auto advance = [&]() __attribute__((always_inline)) {
-        a_pos = b_pos; a_mt = b_mt; a_nt = b_nt;
-        if (a_pos < cnt) b_pos = seek(a_pos + step, b_mt, b_nt);
+    // a_pos = position of the tile computed in the current phase (by this team or by its partner).  A team in the helper role holds
+    // eD = the tile it computed last (its epilogue runs now), eA = tile a_pos, eB = tile a_pos + step (its own next one).
+    int a_pos = pos;
+    TileE eD, eA, eB;
+    auto advance = [&]() __attribute__((always_inline)) { a_pos += step; };
+    auto tile_origin = [&](const TileE e, int& b, int& y0, int& x0) __attribute__((always_inline)) {
+        b = (int)(e.bn & 0xffffu);
+        y0 = (int)(e.yx & 0xffffu);
+        x0 = (int)(e.yx >> 16);
     };
-
-    const int tpi = a.tiles_x * a.tiles_y;
-    auto tile_origin = [&](int mt, int& b, int& y0, int& x0) __attribute__((always_inline)) {
-        b = sdiv(mt, tpi, a.mg_tpi);
-        const int trem = mt - b * tpi;
-        int tyi, txi;
-        tile_rc_s(a, trem, tyi, txi);
-        y0 = tyi * TH;
-        x0 = txi * TW;
-    };
+    auto tile_nt = [](const TileE e) __attribute__((always_inline)) { return (int)(e.bn >> 16); };
 
     // slot counters of the step / chunk that is about to start: weights(h) live in slot hs = h % 3, halo(u) in slot us = u & 1
     int hs = 0, us = 0;
@@ -357,7 +359,6 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
 
     f32x4 acc[NPF][NF];
     Frag<NPF> f;
-    Done done = {0, 0};
     RS_DECL;  // diagnostic builds: counters 0/1 = K-loop cycles / tiles; 4 c .. 4 c + 3 = DMA issue / epilogue / vmcnt wait / barrier of loader
               // step class c = 1 + 2 (epilogue step) + (not a chunk's first step), 20 + c = steps of the class
 
@@ -375,9 +376,9 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     // may see the per-lane offset only, so all four planes of every chunk must exist: Cin % 32 == 0 (the host guards).
     uint32_t hoff[2];
     const char* img_l = nullptr;
-    auto set_load_tile = [&](int mt) __attribute__((always_inline)) {
+    auto set_load_tile = [&](const TileE e) __attribute__((always_inline)) {
         int b, y0, x0;
-        tile_origin(mt, b, y0, x0);
+        tile_origin(e, b, y0, x0);
         img_l = (const char*)a.in0 + (long long)b * a.p0 * plane_in;
         const int lane_ = lane_now();
         // Tiles whose whole 10 x 50 halo (and the row of pad entries behind it) lies inside the image need no per-entry bounds
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     // per tile and lane: pix = byte offset of the lane's pixel of fragment 0 inside a plane (D2S: of its 2 x 2 target block),
     // eoff[n] = offset of the entry of pair n relative to pix, or 0xffffffff where the channel does not exist
     __amdgpu_buffer_rsrc_t orsrc;
-    __amdgpu_buffer_rsrc_t xrsrc;  // FUSE: the block input x (in1) of the finished tile's image
+    u32x4 xrsrc = {0u, 0u, 0u, 0u};  // FUSE: buffer descriptor of the block input x (in1) of the finished tile's image, for inline-asm loads
     uint32_t x_lane = 0;           // FUSE: offset of the lane's 8 bytes of channel fragment 0 relative to e_pix
     uint32_t e_pix = 0, eoff[NT] = {0, 0, 0};
     int e_c = 0, e_y = 0;
@@ -437,8 +438,8 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         const int g = lane_ >> 4, c = lane_ & 15;
         const int lane_cu = 2 * (g & 1) + (g >> 1);  // 16-byte unit of the lane inside a channel-fragment pair's 4 planes (entry16())
         int d_b, d_y0, d_x0;
-        tile_origin(done.mt, d_b, d_y0, d_x0);
-        const int d_nbase = done.nt * BN;
+        tile_origin(eD, d_b, d_y0, d_x0);
+        const int d_nbase = tile_nt(eD) * BN;
         e_c = d_x0 + c;
         e_y = d_y0 + 2 * wq;
         if constexpr (GEO == 1) {
@@ -471,7 +472,11 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
             for (int n = 0; n < NT; ++n) eoff[n] = (uint32_t)(4 * n + lane_cu) * (uint32_t)plane_o;  // planes that do not exist fall out of range
             if constexpr (FUSE) {
                 // x in ACCUMULATOR layout: channels 16 nf + 4 g .. + 3 of the lane's pixel = 8 bytes (g & 1) of plane 2 nf + (g >> 1)
-                xrsrc = __builtin_amdgcn_make_buffer_rsrc((char*)a.in1 + (long long)d_b * a.p1 * plane_o, 0, (int)(uint32_t)(a.p1 * plane_o), 0x00020000);
+                const unsigned long long xb = (unsigned long long)(uintptr_t)((const char*)a.in1 + (long long)d_b * a.p1 * plane_o);
+                xrsrc[0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xb);
+                xrsrc[1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((xb >> 32) & 0xffffu));
+                xrsrc[2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a.p1 * plane_o));  // bytes: loads beyond them return zeros
+                xrsrc[3] = 0x00020000u;
                 x_lane = (uint32_t)(g >> 1) * (uint32_t)plane_o + (uint32_t)(g & 1) * 8u;
             }
         }
@@ -484,8 +489,9 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     // SiLU in SCALAR f32 instructions: the same operations in the same order as silu2(), but no packed-f32 arithmetic --
     // v_pk_mul_f32 / v_pk_add_f32 issue 7 x slower while the SIMD's other wave streams MFMAs (tools/microbench/mb_coissue.hip:
     // 40 cycles each against 9 for v_mul_f32 and 16 for v_exp_f32 / v_rcp_f32)
-    uint32_t f_xq[2][NF][2];  // x of pixel fragment pf in buffer pf & 1 (requested ONE CHUNK AHEAD of its use: the loads come from HBM):
-                              // accumulator layout, two packed pairs per channel fragment
+    typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
+    u32x2_ f_xq[2][NF];    // x of pixel fragment pf in buffer pf & 1 (requested ONE CHUNK AHEAD of its use: the loads come from HBM):
+                           // accumulator layout, two packed pairs per channel fragment (64-bit elements: the inline-asm loads write them in place)
     u32x4 f_zb[NT];        // its z as B operands (live from part A to part D of a chunk)
     auto entry_words = [&](auto e_tag, u32x4& o) __attribute__((always_inline)) {
         constexpr int E = decltype(e_tag)::value;
@@ -554,9 +560,22 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
             const uint32_t o = inside ? off + (uint32_t)(2 * nf) * (uint32_t)plane_o : 0xffffffffu;  // planes >= p1 fall out of range: zeros
-            const auto v = __builtin_amdgcn_raw_buffer_load_b64(xrsrc, (int)o, 0, 0);
-            f_xq[pf & 1][nf][0] = v[0];
-            f_xq[pf & 1][nf][1] = v[1];
+            // Inline asm (as conv3t_kernel): hipcc's waitcnt pass must not see these loads.  It cannot count the conditionally issued DMA
+            // pieces that follow them and waited with vmcnt(0) in front of the gate step -- for the NEXT pixel fragment's loads, issued a
+            // few hundred cycles earlier, whose lines come out of HBM.  The request is a whole chunk older than its use: the closing
+            // vmcnt(0) of the gate step it precedes covers it; x_landed() marks the spot from which the values may be used.
+            // The destination is the ring element itself: a copy behind the asm would read the register before the data arrives.
+            u32x2_& dst = f_xq[pf & 1][nf];
+            const u32x4& xr = xrsrc;  // (named: an asm operand alone does not make a generic lambda capture it)
+            asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(o), "s"(xr) : "memory");
+        }
+    };
+    auto x_landed = [&](auto pf_tag) __attribute__((always_inline)) {
+        constexpr int pf = decltype(pf_tag)::value;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+            u32x2_& r = f_xq[pf & 1][nf];  // (named first: an asm operand alone does not make a generic lambda capture the array)
+            asm volatile("" : "+v"(r));
         }
     };
     auto fuse_z = [&](auto pf_tag) __attribute__((always_inline)) {  // z of pixel fragment pf as B operands
@@ -646,29 +665,35 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         [[maybe_unused]] constexpr int rs_c = 1 + (EN > 0 ? 2 : 0) + (sg == 0 ? 0 : 1);
         static_assert(EN <= 3, "three output registers");
         // VMEM instructions this step issues BEHIND its DMA: stores of the entries, or FUSE's x loads
-        constexpr int VM_AFTER = WK == 1 ? EN : (WK == 2 ? (ES == 0 ? 2 * NF : (ES + 1 < NPF ? NF : 0)) : (WK == 4 ? EN * NT : 0));
+        constexpr int VM_AFTER0 = WK == 1 ? EN : (WK == 2 ? (ES == 0 ? 2 * NF : (ES + 1 < NPF ? NF : 0)) : (WK == 4 ? EN * NT : 0));
+        constexpr int VM_AFTER = VM_AFTER0 + (NSEG == 3 && sg == 0 ? 8 : 0);  // (HALO_LATE, below: the image's pieces stay in flight for a step)
         RS_BEGIN();
         if constexpr (WK == 3) {
-            // x (requested in part A of the chunk before) is needed by the gate GEMM below.  hipcc cannot count the conditional DMA
-            // pieces issued in between and would wait for vmcnt(0) AFTER this step's DMA issue -- for the DMA itself, before any
-            // work.  Naming the registers here makes it wait BEFORE the DMA instead (for loads that have long landed).
-#pragma unroll
-            for (int nf = 0; nf < NF; ++nf) asm volatile("" ::"v"(f_xq[ES & 1][nf][0]), "v"(f_xq[ES & 1][nf][1]));
+            // x of this pixel fragment was requested in part A of the chunk before and is covered by that chunk's closing vmcnt(0) -- except
+            // pixel fragment 0, requested in part A of THIS chunk together with fragment 1's (whose NF loads may stay in flight)
+            if constexpr (ES == 0) wait_vmcnt<NF>();
+            x_landed(ic<ES>{});
         }
-        // ---- this step's DMA: in a chunk's first step the next chunk's halo image (first: its data comes from HBM and takes
-        //      longest), then weight segment (k, sg) + 2 steps ----
-        if constexpr (sg == 0) {
-            if (!last || okB) {
-                const __amdgpu_buffer_rsrc_t h_rsrc = halo_rsrc(last ? 0 : k + 1);
-                // (opaque: hipcc would otherwise keep the eight piece addresses of a slot alive from one chunk to the next but one as
-                // spilled SGPRs -- a v_writelane / v_readlane pair each, vector instructions the helper role is short of)
-                uint32_t h_off = (uint32_t)(us ^ 1) * (uint32_t)A_SLOT;
-                asm volatile("" : "+s"(h_off));
-                char* const h_dst = smem + h_off;
-                halo_piece(ic<0>{}, h_rsrc, h_dst); halo_piece(ic<1>{}, h_rsrc, h_dst); halo_piece(ic<2>{}, h_rsrc, h_dst);
-                halo_piece(ic<3>{}, h_rsrc, h_dst); halo_piece(ic<4>{}, h_rsrc, h_dst); halo_piece(ic<5>{}, h_rsrc, h_dst);
-                halo_piece(ic<6>{}, h_rsrc, h_dst); halo_piece(ic<7>{}, h_rsrc, h_dst);
-            }
+        // ---- this step's DMA: in a chunk's first step the next chunk's halo image, and weight segment (k, sg) + 2 steps.
+        //      NSEG = 2: the image first (its data comes from HBM and takes longest) and landed by the end of this step -- the compute role
+        //      reads its first fragments in the chunk's SECOND step.  NSEG = 3 (HALO_LATE): those reads come in the third step, so the
+        //      image goes out BEHIND the weights and this step's closing wait leaves its eight pieces in flight (the next step's covers
+        //      them): a step more for the lines to come out of HBM.  For that count to be exact the pieces are issued on every path: where
+        //      no tile follows they re-fetch the current tile's first image into the free slot. ----
+        constexpr bool HALO_LATE = NSEG == 3;
+        auto halo_image = [&]() __attribute__((always_inline)) {
+            const __amdgpu_buffer_rsrc_t h_rsrc = halo_rsrc(last ? 0 : k + 1);
+            // (opaque: hipcc would otherwise keep the eight piece addresses of a slot alive from one chunk to the next but one as
+            // spilled SGPRs -- a v_writelane / v_readlane pair each, vector instructions the helper role is short of)
+            uint32_t h_off = (uint32_t)(us ^ 1) * (uint32_t)A_SLOT;
+            asm volatile("" : "+s"(h_off));
+            char* const h_dst = smem + h_off;
+            halo_piece(ic<0>{}, h_rsrc, h_dst); halo_piece(ic<1>{}, h_rsrc, h_dst); halo_piece(ic<2>{}, h_rsrc, h_dst);
+            halo_piece(ic<3>{}, h_rsrc, h_dst); halo_piece(ic<4>{}, h_rsrc, h_dst); halo_piece(ic<5>{}, h_rsrc, h_dst);
+            halo_piece(ic<6>{}, h_rsrc, h_dst); halo_piece(ic<7>{}, h_rsrc, h_dst);
+        };
+        if constexpr (sg == 0 && !HALO_LATE) {
+            if (!last || okB) halo_image();
         }
         {
             constexpr bool same = sg + 2 < NSEG;
@@ -688,6 +713,7 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
             if constexpr (WP > 6) wseg_piece(ic<6>{}, wsrc, w_pieces, w_dst, lo);
             static_assert(WP <= 7, "seven weight pieces per wave and step");
         }
+        if constexpr (sg == 0 && HALO_LATE) halo_image();
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("" ::: "memory");
         RS_LAP(4 * rs_c);
@@ -720,7 +746,7 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
                 prime(next3(hs), us ^ 1);
             } else {
                 if (k + 2 == nchunks && okB) {  // the next step requests tB's first halo image
-                    set_load_tile(b_mt);
+                    set_load_tile(eB);
                 }
             }
         }
@@ -764,12 +790,14 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     };
     auto loader_phase = [&](auto epi_tag) __attribute__((always_inline)) {
         constexpr bool DO_EPI = decltype(epi_tag)::value != 0;
-        wA = wsrc_of(a_nt);
-        okB = b_pos < cnt;
-        wB = wsrc_of(okB ? b_nt : a_nt);
+        wA = wsrc_of(tile_nt(eA));
+        okB = a_pos + step < cnt;
+        wB = wsrc_of(tile_nt(okB ? eB : eA));
+        // the two tiles behind eB: eA / eB of this team's NEXT helper phase (two phases on), requested now, taken over at the end of this phase
+        const TileE eA2 = tile_at(a_pos + 2 * step), eB2 = tile_at(a_pos + 3 * step);
         if constexpr (DO_EPI) {
             RS_BEGIN();
-            set_load_tile(a_mt);
+            set_load_tile(eA);
             epi_setup();
             RS_FENCE();
             RS_LAP(27);
@@ -801,18 +829,22 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
                     plain_chunks(6);
                 }
             } else {
-                loader_chunk(ic<0>{}, ic<3>{}, ic<3>{}, ic<0>{}, 0);
-                loader_chunk(ic<6>{}, ic<3>{}, ic<3>{}, ic<0>{}, 1);
+                constexpr int F3 = NSEG == 3 ? 2 : 3;  // entries of a chunk's first step (three steps: 2 + 2 + 2)
+                loader_chunk(ic<0>{}, ic<F3>{}, ic<6 - F3>{}, ic<0>{}, 0);
+                loader_chunk(ic<6>{}, ic<F3>{}, ic<6 - F3>{}, ic<0>{}, 1);
                 if (nchunks == 3) {
-                    loader_chunk(ic<12>{}, ic<3>{}, ic<3>{}, ic<1>{}, 2);
+                    loader_chunk(ic<12>{}, ic<F3>{}, ic<6 - F3>{}, ic<1>{}, 2);
                 } else {
-                    loader_chunk(ic<12>{}, ic<3>{}, ic<3>{}, ic<0>{}, 2);
+                    loader_chunk(ic<12>{}, ic<F3>{}, ic<6 - F3>{}, ic<0>{}, 2);
                     plain_chunks(3);
                 }
             }
         } else {
             plain_chunks(0);
         }
+        // this team computes eB next (its epilogue runs in the helper phase after that)
+        eD = eB; eA = eA2; eB = eB2;
+        asm volatile("" ::"s"(eA.yx), "s"(eA.bn), "s"(eB.yx), "s"(eB.bn));  // (landed here: no scalar load in flight beside the K loop's counted waits)
     };
 
     // ------------------------------------------------------------------------------------------------
@@ -875,12 +907,13 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         const int adv = (NSEG * nchunks) % 3;
         hs = hs + adv >= 3 ? hs + adv - 3 : hs + adv;
         us ^= nchunks & 1;
-        done = Done{a_mt, a_nt};
     };
     auto final_fuse_pf = [&](auto pf_tag) __attribute__((always_inline)) {
         constexpr int pf = decltype(pf_tag)::value;
         fuse_x(pf_tag);
         fuse_z(pf_tag);
+        wait_vmcnt<0>();  // (no partner, no DMA: the plain sequence)
+        x_landed(pf_tag);
         fuse_c(pf_tag);
         entry_whole(ic<3 * pf>{}); entry_whole(ic<3 * pf + 1>{}); entry_whole(ic<3 * pf + 2>{});
     };
@@ -898,8 +931,11 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     // ------------------------------------------------------------------------------------------------
     if (team == 1) {
         // prologue: chunk 0 of the first tile (halo image + the first two weight segments), published by B_0
-        wA = wsrc_of(a_nt);
-        set_load_tile(a_mt);
+        eA = tile_at(a_pos);
+        eB = tile_at(a_pos + step);
+        eD = eA;  // (unused: the first helper phase has no epilogue)
+        wA = wsrc_of(tile_nt(eA));
+        set_load_tile(eA);
         {
             const __amdgpu_buffer_rsrc_t r0 = halo_rsrc(0);
             halo_piece(ic<0>{}, r0, smem); halo_piece(ic<1>{}, r0, smem); halo_piece(ic<2>{}, r0, smem); halo_piece(ic<3>{}, r0, smem);
@@ -928,6 +964,11 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         advance();
         if (a_pos >= cnt) { RS_DUMP(); return; }
     } else {
+        // its first helper phase (after tile a_pos) works on the tiles behind it
+        eD = tile_at(a_pos);
+        eA = tile_at(a_pos + step);
+        eB = tile_at(a_pos + 2 * step);
+        asm volatile("" ::"s"(eD.yx), "s"(eD.bn), "s"(eA.yx), "s"(eA.bn), "s"(eB.yx), "s"(eB.bn));
         __builtin_amdgcn_s_barrier();  // B_0
         if constexpr (FUSE) zero_acc();
         prime(0, 0);

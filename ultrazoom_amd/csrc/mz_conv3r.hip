@@ -2,7 +2,9 @@
 #include "mz_conv3r.h"
 
 #ifndef MZ_R_NSEG
-#define MZ_R_NSEG 2  // weight segments per chunk of the plain / sub-pixel variants (the fused variant always uses 3)
+#define MZ_R_NSEG 3  // weight segments per chunk of the plain / sub-pixel variants (the fused variant always uses 3).  Three since round 4:
+                     // with the halo image issued behind the weights and left in flight for a step (HALO_LATE, mz_conv3r.h) the 3- and
+                     // 6-chunk layers run 3.5 - 6 % faster than with two segments, the deep layers the same (tools/ab_libs.sh base n3)
 #endif
 
 namespace mz {

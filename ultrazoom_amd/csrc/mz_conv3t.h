@@ -166,38 +166,35 @@ __global__ __launch_bounds__(512) void conv3t_kernel(const ConvArgs a) {
     const int nchunks = a.nchunks16;       // 32-channel chunks: 3, or >= 6 (the host guards)
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
-    // ---- tile walk (as conv3r_kernel: an XCD's contiguous id range, strided by the workgroups of that XCD) ----
+    // ---- tile walk (as conv3r_kernel: the host's tile list, an XCD's contiguous range of it strided by the workgroups of that XCD;
+    // a tile's coordinates are one scalar load, requested two tiles ahead at the start of a helper phase) ----
     const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3, step = gridDim.x >> 3;
     const int q = a.grid >> 3, rem = a.grid & 7;
     const int cnt = q + (xcd < rem ? 1 : 0);
     const int base = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
-    auto seek = [&](int i, int& mt) __attribute__((always_inline)) {
-        int nt_;
-        while (i < cnt && !tile_of_s(a, base + i, mt, nt_)) i += step;
-        return i;
+    if (pos >= cnt) return;  // uniform over the workgroup
+    typedef uint32_t TabE __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(4))) TabE* TabPtr;
+    const TabPtr tab = (TabPtr)(uintptr_t)a.tile_tab + base;
+    struct TileE { uint32_t yx, bn; };  // y0 | x0 << 16, image (the N tile is always 0 here)
+    auto tile_at = [&](int i) __attribute__((always_inline)) {
+        const TabE e = tab[i];
+        return TileE{e[0], e[1]};
     };
-    int a_pos, a_mt = 0, b_pos, b_mt = 0;  // tA = the tile the workgroup is computing (or about to), tB = the one after it
-    a_pos = seek(pos, a_mt);
-    if (a_pos >= cnt) return;  // uniform over the workgroup
-    b_pos = seek(a_pos + step, b_mt);
-    auto advance = [&]() __attribute__((always_inline)) {
-        a_pos = b_pos; a_mt = b_mt;
-        if (a_pos < cnt) b_pos = seek(a_pos + step, b_mt);
-    };
-    const int tpi = a.tiles_x * a.tiles_y;
-    auto tile_origin = [&](int mt, int& b, int& y0, int& x0) __attribute__((always_inline)) {
-        b = sdiv(mt, tpi, a.mg_tpi);
-        const int trem = mt - b * tpi;
-        int tyi, txi;
-        tile_rc_s(a, trem, tyi, txi);
-        y0 = tyi * TH;
-        x0 = txi * TW;
+    // a_pos = position of the tile computed in the current phase.  A team in the helper role holds eD = the tile it computed last (its
+    // epilogue runs now), eA = tile a_pos, eB = tile a_pos + step (its own next one).
+    int a_pos = pos;
+    TileE eD, eA, eB;
+    auto advance = [&]() __attribute__((always_inline)) { a_pos += step; };
+    auto tile_origin = [&](const TileE e, int& b, int& y0, int& x0) __attribute__((always_inline)) {
+        b = (int)(e.bn & 0xffffu);
+        y0 = (int)(e.yx & 0xffffu);
+        x0 = (int)(e.yx >> 16);
     };
 
     int us = 0;  // halo slot of the chunk that is about to start
     f32x4 acc[NPF][NF];
     Frag f;
-    int done_mt = 0;
     RS_DECL;  // diagnostic builds (-DMZ_DIAG, mz_diag.h; tools/stamp_probe_t.py): counters 0 / 1 = K-loop cycles / tiles, 2 = final epilogue;
               // step class c = (chunk's first step ? 0 : 1) + (epilogue work ? 2 : 0): 4 c + 4 .. + 7 = request + DMA issue / epilogue /
               // vmcnt wait / barrier, 24 + c = steps of the class; 3 = phase start (offsets, epilogue setup)
@@ -212,9 +209,9 @@ __global__ __launch_bounds__(512) void conv3t_kernel(const ConvArgs a) {
     // not see scalar offsets), so a tile costs four per-lane offsets.
     uint32_t hoff[4];
     const char* img_l = nullptr;
-    auto set_load_tile = [&](int mt) __attribute__((always_inline)) {
+    auto set_load_tile = [&](const TileE e) __attribute__((always_inline)) {
         int b, y0, x0;
-        tile_origin(mt, b, y0, x0);
+        tile_origin(e, b, y0, x0);
         img_l = (const char*)a.in0 + (long long)b * a.p0 * plane_in;
         const int lane_ = lane_now();
         // tiles whose whole halo (and the row of pad entries behind it) lies inside the image need no per-entry bounds test
@@ -267,7 +264,7 @@ __global__ __launch_bounds__(512) void conv3t_kernel(const ConvArgs a) {
         if (wq == 0) glds16(src + 8192, dst + 8192);
     };
 
-    // ---- epilogue of the finished tile `done_mt` ----
+    // ---- epilogue of the finished tile eD ----
     __amdgpu_buffer_rsrc_t orsrc;
     u32x4 xrsrc = {0u, 0u, 0u, 0u};  // FUSE: buffer descriptor of the block input x (in1) of the finished tile's image, for inline-asm loads
     uint32_t e_pix = 0, eoff1 = 0, eoff2 = 0, x_lane = 0;
@@ -276,7 +273,7 @@ __global__ __launch_bounds__(512) void conv3t_kernel(const ConvArgs a) {
         const int lane_ = lane_now();
         const int g = lane_ >> 4, c = lane_ & 15;
         int d_b, d_y0, d_x0;
-        tile_origin(done_mt, d_b, d_y0, d_x0);
+        tile_origin(eD, d_b, d_y0, d_x0);
         e_c = d_x0 + c;
         e_c2 = e_c + 16 * (g & 1);  // entries of channel fragment 2: the lane's pixel belongs to pixel fragment 2 k + (g & 1)
         e_y = d_y0 + RPW * wq;
@@ -527,7 +524,7 @@ __global__ __launch_bounds__(512) void conv3t_kernel(const ConvArgs a) {
                 }
                 prime(us ^ 1);
             } else {
-                if (k + 2 == nchunks && okB) set_load_tile(b_mt);  // the next step requests tB's first halo image
+                if (k + 2 == nchunks && okB) set_load_tile(eB);  // the next step requests tB's first halo image
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -566,9 +563,11 @@ __global__ __launch_bounds__(512) void conv3t_kernel(const ConvArgs a) {
     };
     auto loader_phase = [&](auto epi_tag) __attribute__((always_inline)) {
         constexpr bool DO_EPI = decltype(epi_tag)::value != 0;
-        okB = b_pos < cnt;
+        okB = a_pos + step < cnt;
+        // the two tiles behind eB: eA / eB of this team's NEXT helper phase (two phases on), requested now, taken over at the end of this phase
+        const TileE eA2 = tile_at(a_pos + 2 * step), eB2 = tile_at(a_pos + 3 * step);
         RS_BEGIN();
-        set_load_tile(a_mt);
+        set_load_tile(eA);
         if constexpr (DO_EPI) {
             epi_setup();
             RS_FENCE();
@@ -593,6 +592,9 @@ __global__ __launch_bounds__(512) void conv3t_kernel(const ConvArgs a) {
         } else {
             plain_chunks(0);
         }
+        // this team computes eB next (its epilogue runs in the helper phase after that)
+        eD = eB; eA = eA2; eB = eB2;
+        asm volatile("" ::"s"(eA.yx), "s"(eA.bn), "s"(eB.yx), "s"(eB.bn));  // (landed here: no scalar load in flight beside the K loop's counted waits)
     };
 
     // ------------------------------------------------------------------------------------------------
@@ -620,7 +622,6 @@ __global__ __launch_bounds__(512) void conv3t_kernel(const ConvArgs a) {
         RS_LAP(0);
         RS_COUNT(1);
         us ^= nchunks & 1;
-        done_mt = a_mt;
     };
     auto final_epilogue = [&]() __attribute__((always_inline)) {
         epi_setup();
@@ -647,7 +648,10 @@ __global__ __launch_bounds__(512) void conv3t_kernel(const ConvArgs a) {
     // ------------------------------------------------------------------------------------------------
     if (team == 1) {
         // prologue: chunk 0 of the first tile (halo image + its first two weight segments), published by B_0
-        set_load_tile(a_mt);
+        eA = tile_at(a_pos);
+        eB = tile_at(a_pos + step);
+        eD = eA;  // (unused: the first helper phase has no epilogue)
+        set_load_tile(eA);
         halo_half(ic<0>{}, 0, 0);
         halo_half(ic<1>{}, 0, 0);
         weight_segment(0, 0);
@@ -664,6 +668,11 @@ __global__ __launch_bounds__(512) void conv3t_kernel(const ConvArgs a) {
         advance();
         if (a_pos >= cnt) { RS_DUMP(); return; }
     } else {
+        // its first helper phase (after tile a_pos) works on the tiles behind it
+        eD = tile_at(a_pos);
+        eA = tile_at(a_pos + step);
+        eB = tile_at(a_pos + 2 * step);
+        asm volatile("" ::"s"(eD.yx), "s"(eD.bn), "s"(eA.yx), "s"(eA.bn), "s"(eB.yx), "s"(eB.bn));
         __builtin_amdgcn_s_barrier();  // B_0
         if constexpr (FUSE) {
 #pragma unroll

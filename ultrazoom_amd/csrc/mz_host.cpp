@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <string>
 #include <unordered_map>
@@ -222,6 +223,12 @@ struct mz_handle {
     bool prof = false;
     std::vector<ProfRec> recs;
     size_t recs_used = 0;
+    // tile lists of the role-alternating kernels (Runner::tile_table): one per launch geometry, built on first use
+    std::map<std::vector<int>, std::pair<void*, int>> tile_tabs;
+    ~mz_handle() {
+        for (auto& t : tile_tabs)
+            if (t.second.first) (void)hipFree(t.second.first);
+    }
 };
 
 static void add_slot(mz_handle* h, const std::string& name, int kind, std::initializer_list<int64_t> shape) {
@@ -702,6 +709,54 @@ struct Runner {
         a.mg_bsz = magic(a.tiles_x > 0 ? 4LL * a.tiles_x : 1);
     }
 
+    // conv3r_kernel / conv3t_kernel: the launch's tiles in walk order as a table in HBM (ConvArgs::tile_tab), so that the kernels'
+    // helper role -- the critical path of their short tiles -- reads a tile's coordinates with one scalar load instead of running
+    // the divisions of the group walk (tile_of_s / tile_rc_s, mz_device.h) three times per phase.  The order IS that walk's: ids
+    // 0 .. grid - 1 in gm x gn groups, the tiles of an image in block rows of four tile rows (blk4), padding ids dropped.  Needs
+    // pick_order() done; sets a.tile_tab, a.grid (= tiles listed) and a.persist.  One table per geometry, kept with the handle.
+    void tile_table(ConvArgs& a, int th, int tw) {
+        if (rc) return;
+        if (a.B >= 65536 || a.ntiles >= 65536 || a.tiles_y * th >= 65536 || a.tiles_x * tw >= 65536) {
+            rc = fail(MZ_ERR_INVALID_ARGUMENT, "tile table: image, batch or N-tile index beyond 16 bits");
+            return;
+        }
+        const int pad = 4 * ((persist_wgs > 256 ? persist_wgs : 256) / 8) + 8;
+        const std::vector<int> key = {th, tw, a.B, a.tiles_x, a.tiles_y, a.ntiles, a.gm, a.gn, a.grid, a.blk4, pad};
+        auto it = h->tile_tabs.find(key);
+        if (it == h->tile_tabs.end()) {
+            std::vector<uint32_t> t;
+            t.reserve(2 * ((size_t)a.mtiles * a.ntiles + pad));
+            const int tpi = a.tiles_x * a.tiles_y, gsz = a.gm * a.gn;
+            for (int L = 0; L < a.grid; ++L) {
+                const int group = L / gsz, within = L % gsz;
+                const int gi_n = group / a.groups_m, gi_m = group % a.groups_m;
+                const int mt = gi_m * a.gm + within / a.gn, nt = gi_n * a.gn + within % a.gn;
+                if (mt >= a.mtiles || nt >= a.ntiles) continue;
+                const int b = mt / tpi, trem = mt % tpi;
+                int tyi, txi;
+                if (!a.blk4) {
+                    tyi = trem / a.tiles_x; txi = trem % a.tiles_x;
+                } else {
+                    const int bsz = 4 * a.tiles_x, br = trem / bsz, rem = trem % bsz;
+                    const int rows = std::min(4, a.tiles_y - 4 * br);
+                    txi = rem / rows; tyi = 4 * br + rem % rows;
+                }
+                t.push_back((uint32_t)(tyi * th) | (uint32_t)(txi * tw) << 16);
+                t.push_back((uint32_t)b | (uint32_t)nt << 16);
+            }
+            const int n = (int)(t.size() / 2);
+            t.resize(t.size() + 2 * (size_t)pad, 0u);
+            void* d = nullptr;
+            if (check(hipMalloc(&d, t.size() * 4), "tile table")) return;
+            if (check(hipMemcpy(d, t.data(), t.size() * 4, hipMemcpyHostToDevice), "tile table upload")) { (void)hipFree(d); return; }
+            it = h->tile_tabs.emplace(key, std::make_pair(d, n)).first;
+        }
+        a.tile_tab = it->second.first;
+        a.grid = it->second.second;
+        const int need = (a.grid + 7) / 8 * 8;
+        a.persist = need < persist_wgs ? need : persist_wgs;
+    }
+
     // conv3x3, pad 1 (model.py:742-748, 900-909, 1010). epi: STORE / D2S / FINAL
     void conv3(const ConvW& c, const void* in, void* out, int B, int H, int W, int epi, int silu, int Hout, int Wout,
                const void* img = nullptr, int R = 0, int clamp = 0, const void* zero_override = nullptr,
@@ -768,8 +823,8 @@ struct Runner {
             pick_order(a, c, px * c.cp0 * sz);
             a.s16 = 1; a.wpk16 = c.packed16t; a.nchunks16 = c.nchunks16t;
             if (t_fuse) a.wmix16 = mixf->packed16t;
-            const int need = (a.grid + 7) / 8 * 8;
-            a.persist = need < persist_wgs ? need : persist_wgs;
+            tile_table(a, 12, 64);
+            if (rc) return;
             const double extra_bytes = epi == EPI_FUSEDMIX ? px * c.cout * sz : 0.0;
             ProfRec* r;
             prof_begin(r, 2.0 * px * 9.0 * c.cin * c.cout + extra_flops, px * (c.cin + c.cout) * sz + 9.0 * c.cin * c.cout * sz + extra_bytes, 1);
@@ -810,8 +865,8 @@ struct Runner {
             pick_order(a, c, px * c.cp0 * sz);
             a.s16 = 1; a.wpk16 = c.packed16; a.nchunks16 = c.nchunks16;
             a.wmix16 = mixf->packed16r;
-            const int need = (a.grid + 7) / 8 * 8;
-            a.persist = need < persist_wgs ? need : persist_wgs;
+            tile_table(a, 8, 48);
+            if (rc) return;
             ProfRec* r;
             prof_begin(r, 2.0 * px * 9.0 * c.cin * c.cout + extra_flops, px * (c.cin + c.cout) * sz + 9.0 * c.cin * c.cout * sz + px * c.cout * sz, 1);
             if (r) { r->kind = 0; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.gm * 1000 + a.gn; }
@@ -827,8 +882,13 @@ struct Runner {
             a.mtiles = B * a.tiles_x * a.tiles_y;
             pick_order(a, c, px * c.cp0 * sz);
             a.s16 = 1; a.wpk16 = c.packed16; a.nchunks16 = c.nchunks16;
-            const int need = (a.grid + 7) / 8 * 8;
-            a.persist = need < persist_wgs ? need : persist_wgs;
+            if (use_r) {
+                tile_table(a, 8, tw_q);
+                if (rc) return;
+            } else {
+                const int need = (a.grid + 7) / 8 * 8;
+                a.persist = need < persist_wgs ? need : persist_wgs;
+            }
             ProfRec* r;
             prof_begin(r, 2.0 * px * 9.0 * c.cin * c.cout, px * (c.cin + c.cout) * sz + 9.0 * c.cin * c.cout * sz, 1);
             if (r) { r->kind = 0; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.gm * 1000 + a.gn; }

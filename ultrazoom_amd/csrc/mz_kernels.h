@@ -73,6 +73,8 @@ struct ConvArgs {
     int s16;           // persistent launches of 16-bit types: use the 16x16x32-MFMA kernel (needs wpk16)
     const void* wpk16; // weights packed for it: [ntile][32-channel chunk][tap][2*nt][64 lanes][16 B]
     int nchunks16;     // 32-channel chunks
+    const void* tile_tab;  // conv3r / conv3t: the launch's tiles in walk order, uint2 {y0 | x0 << 16, image | N tile << 16} each, padded with
+                           // 4 * persist / 8 + 8 entries; a.grid = its length (mz_host.cpp: tile_table())
     int geo;           // conv3r_kernel: pixel-tile geometry, 0 = 8 x 48 (six pixel fragments per wave), 1 = 8 x 40 (five)
     const void* wmix16; // EPI_FUSEDMIX on the 16x16x32 kernel: gate weights packed [2*nt K-steps][2*nt][64 lanes][16 B]
     const float* film_gamma;  // EPI_STORE on conv3s_kernel only: per-image per-channel affine gamma * y + beta ahead of the SiLU
