@@ -171,6 +171,12 @@ int mz_debug_read(unsigned long long* host_dst);
  * "conv_kernel_mix"): lets a test that compares two kernels assert that it really ran both.  No reference counterpart. */
 const char* mz_debug_last_kernel(void);
 
+/* Host-only (no GPU): the tile list the role-alternating 3x3 kernels (conv3r / conv3t) walk -- B images of tiles_y x tiles_x pixel tiles
+ * of th x tw pixels, ntiles N tiles, in groups of gm pixel tiles x gn N tiles (blk4 != 0: the tiles of an image in block rows of four
+ * tile rows).  Entry i = out[2 i], out[2 i + 1] = {y0 | x0 << 16, image | N tile << 16}; at most `cap` entries are written.  Returns the
+ * number of tiles listed (== B * tiles_y * tiles_x * ntiles), negative on bad arguments.  No reference counterpart. */
+int mz_debug_tile_list(int B, int tiles_y, int tiles_x, int ntiles, int gm, int gn, int blk4, int th, int tw, unsigned int* out, int cap);
+
 /* Hardware probe (ultrazoom_amd/csrc/mz_probe.hip; tests/test_store_hazard_gpu.py): on every CU, 16-byte buffer stores each followed --
  * `wait_states` (0, 1, 2) wait states later -- by a vector instruction that overwrites data register `dword` (0..3) of the store:
  * follower 0 v_mov_b32, 1 v_mul_f32, 2 v_cvt_pk_bf16_f32, 3 v_exp_f32, 4 v_pk_mul_f32, 5 v_mfma_f32_16x16x32_bf16;

@@ -88,3 +88,38 @@ def test_weights_cannot_be_set_without_a_gpu():
         h.set_weight("stem.conv.bias", 0x1000, (17,), 0)
     assert ei.value.code == -3
     h.close()
+
+
+@pytest.mark.parametrize(
+    "geom",
+    [
+        # B, tiles_y, tiles_x, ntiles, gm, gn, blk4, th, tw
+        (3, 135, 40, 2, 16, 2, 1, 8, 48),   # the headline's 1080 x 1920 level: 96 -> 192
+        (3, 17, 5, 8, 4, 8, 1, 8, 48),      # 135 x 240, 1536 -> 768: more N tiles than a group is wide
+        (3, 17, 6, 16, 2, 16, 0, 8, 40),    # the 8 x 40 geometry, row-major walk
+        (2, 7, 3, 3, 5, 2, 1, 8, 48),       # partial groups in both directions, last block row of three tile rows
+        (1, 1, 1, 1, 32, 1, 1, 12, 64),     # one tile
+        (32, 45, 15, 1, 32, 1, 1, 12, 64),  # conv3t on BASELINE configs[1]'s level 1
+    ],
+)
+def test_tile_list_lists_every_tile_once(geom):
+    """The tile list the role-alternating kernels walk (mz_host.cpp: tile_list(), uploaded by Runner::tile_table()): every (image, tile row,
+    tile column, N tile) exactly once, tile origins on the tile grid, and the N tiles of a group's pixel tile next to each other."""
+    B, ty, tx, ntiles, gm, gn, blk4, th, tw = geom
+    lib = ctypes.CDLL(str(_ffi.LIB_PATH))
+    lib.mz_debug_tile_list.restype = ctypes.c_int
+    total = B * ty * tx * ntiles
+    buf = (ctypes.c_uint * (2 * total))()
+    n = lib.mz_debug_tile_list(B, ty, tx, ntiles, gm, gn, blk4, th, tw, buf, total)
+    assert n == total
+    seen = set()
+    for i in range(n):
+        yx, bn = buf[2 * i], buf[2 * i + 1]
+        y0, x0, b, nt = yx & 0xFFFF, yx >> 16, bn & 0xFFFF, bn >> 16
+        assert y0 % th == 0 and x0 % tw == 0 and y0 // th < ty and x0 // tw < tx and b < B and nt < ntiles
+        seen.add((b, y0, x0, nt))
+    assert len(seen) == total
+    if gn >= 2 and ntiles >= 2:  # consecutive entries share the pixel tile inside a group's row of N tiles
+        same = sum(1 for i in range(n - 1) if buf[2 * i] == buf[2 * i + 2] and (buf[2 * i + 1] & 0xFFFF) == (buf[2 * i + 3] & 0xFFFF))
+        assert same >= n // 3
+    assert lib.mz_debug_tile_list(0, ty, tx, ntiles, gm, gn, blk4, th, tw, buf, total) < 0

@@ -225,7 +225,8 @@ __device__ __forceinline__ void gate_halves(f32x4 (&beta)[NF], const u32x4 (&xf)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
-            if constexpr (ks < NT) mma16<TT>(beta[part * NT + i], wa[i], xf[ks]);
+            if constexpr (ks == 0) mma16_first<TT>(beta[part * NT + i], wa[i], xf[0]);  // (the gate's first K step writes beta: nobody clears it)
+            else if constexpr (ks < NT) mma16<TT>(beta[part * NT + i], wa[i], xf[ks]);
             else mma16<TT>(beta[part * NT + i], wa[i], zf[ks - NT]);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -590,10 +591,9 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
             f_zb[m] = q;
         }
     };
-    // part A of chunk pf: x of the NEXT pixel fragment (of the first two in chunk 0), z of this one
+    // part A of chunk pf: x of the NEXT pixel fragment (fragment 0's: see loader_step()), z of this one
     auto fuse_a = [&](auto pf_tag) __attribute__((always_inline)) {
         constexpr int pf = decltype(pf_tag)::value;
-        if constexpr (pf == 0) fuse_x(ic<0>{});
         if constexpr (pf + 1 < NPF) fuse_x(ic<(pf + 1 < NPF ? pf + 1 : 0)>{});
         fuse_z(pf_tag);
     };
@@ -604,8 +604,6 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         u32x4 xb[NT];
 #pragma unroll
         for (int m = 0; m < NT; ++m) xb[m] = u32x4{f_xq[pf & 1][2 * m][0], f_xq[pf & 1][2 * m][1], f_xq[pf & 1][2 * m + 1][0], f_xq[pf & 1][2 * m + 1][1]};
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf) acc[pf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
         u32x4 wa[NT], wb[NT];
         gate_reads<0, 0>(wa, mix_lane);
         gate_halves<TT, 0>(acc[pf], xb, f_zb, wa, wb, mix_lane);
@@ -665,15 +663,13 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
         [[maybe_unused]] constexpr int rs_c = 1 + (EN > 0 ? 2 : 0) + (sg == 0 ? 0 : 1);
         static_assert(EN <= 3, "three output registers");
         // VMEM instructions this step issues BEHIND its DMA: stores of the entries, or FUSE's x loads
-        constexpr int VM_AFTER0 = WK == 1 ? EN : (WK == 2 ? (ES == 0 ? 2 * NF : (ES + 1 < NPF ? NF : 0)) : (WK == 4 ? EN * NT : 0));
+        constexpr int VM_AFTER0 = WK == 1 ? EN : (WK == 2 ? (ES + 1 < NPF ? NF : 0) : (WK == 4 ? EN * NT : 0));
         constexpr int VM_AFTER = VM_AFTER0 + (NSEG == 3 && sg == 0 ? 8 : 0);  // (HALO_LATE, below: the image's pieces stay in flight for a step)
         RS_BEGIN();
-        if constexpr (WK == 3) {
-            // x of this pixel fragment was requested in part A of the chunk before and is covered by that chunk's closing vmcnt(0) -- except
-            // pixel fragment 0, requested in part A of THIS chunk together with fragment 1's (whose NF loads may stay in flight)
-            if constexpr (ES == 0) wait_vmcnt<NF>();
-            x_landed(ic<ES>{});
-        }
+        // x of a pixel fragment is requested in part A of the chunk before its gate step (covered by that chunk's closing vmcnt(0)); pixel
+        // fragment 0's at the head of the tile's first step, AHEAD of the step's DMA: that step's closing wait covers it too
+        if constexpr (WK == 2 && ES == 0) fuse_x(ic<0>{});
+        if constexpr (WK == 3) x_landed(ic<ES>{});
         // ---- this step's DMA: in a chunk's first step the next chunk's halo image, and weight segment (k, sg) + 2 steps.
         //      NSEG = 2: the image first (its data comes from HBM and takes longest) and landed by the end of this step -- the compute role
         //      reads its first fragments in the chunk's SECOND step.  NSEG = 3 (HALO_LATE): those reads come in the third step, so the
@@ -816,7 +812,7 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
                 }
             } else if (nchunks >= 6) {
                 // The 18 entries are spread over the tile's first six chunks where it has six (1 + 2 per chunk: the first step also
-                // carries the halo image), else over its first three (3 + 3).
+                // carries the halo image; with three steps per chunk 1 + 1 + 1), else over its first three.
                 loader_chunk(ic<0>{}, ic<1>{}, ic<2>{}, ic<0>{}, 0);
                 loader_chunk(ic<3>{}, ic<1>{}, ic<2>{}, ic<0>{}, 1);
                 loader_chunk(ic<6>{}, ic<1>{}, ic<2>{}, ic<0>{}, 2);

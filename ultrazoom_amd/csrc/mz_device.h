@@ -316,6 +316,13 @@ template <> __device__ __forceinline__ void mma16<TF16>(f32x4& acc, const u32x4&
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, w), __builtin_bit_cast(f16x8_t, x), acc, 0, 0, 0);
 }
 
+// the same MFMA WRITING the accumulator (C = 0 as an inline constant): the first K step of a sum needs no cleared registers
+template <class TT> __device__ __forceinline__ void mma16_first(f32x4& acc, const u32x4& w, const u32x4& x) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (TT::IS_BF16) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x), zero, 0, 0, 0);
+    else acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, w), __builtin_bit_cast(f16x8_t, x), zero, 0, 0, 0);
+}
+
 // ---- store epilogue of the 16x16x32 kernels: one 16-byte plane entry (8 channels) from a pair of accumulator fragments ----
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));

@@ -628,6 +628,30 @@ static float inv_sigmoid(float alpha) {
     return std::isfinite(v) ? v : 3.402823466e+38f;
 }
 
+// The tiles of a launch in walk order, two words each: {y0 | x0 << 16, image | N tile << 16}.  The order is the group walk of
+// mz_device.h (tile_of / tile_rc): ids 0 .. a.grid - 1 in groups of gm pixel tiles x gn N tiles, the tiles of an image in block rows of
+// four tile rows where a.blk4 is set, padding ids of partial groups dropped.
+static void tile_list(const ConvArgs& a, int th, int tw, std::vector<uint32_t>& t) {
+    const int tpi = a.tiles_x * a.tiles_y, gsz = a.gm * a.gn;
+    for (int L = 0; L < a.grid; ++L) {
+        const int group = L / gsz, within = L % gsz;
+        const int gi_n = group / a.groups_m, gi_m = group % a.groups_m;
+        const int mt = gi_m * a.gm + within / a.gn, nt = gi_n * a.gn + within % a.gn;
+        if (mt >= a.mtiles || nt >= a.ntiles) continue;
+        const int b = mt / tpi, trem = mt % tpi;
+        int tyi, txi;
+        if (!a.blk4) {
+            tyi = trem / a.tiles_x; txi = trem % a.tiles_x;
+        } else {
+            const int bsz = 4 * a.tiles_x, br = trem / bsz, rem = trem % bsz;
+            const int rows = std::min(4, a.tiles_y - 4 * br);
+            txi = rem / rows; tyi = 4 * br + rem % rows;
+        }
+        t.push_back((uint32_t)(tyi * th) | (uint32_t)(txi * tw) << 16);
+        t.push_back((uint32_t)b | (uint32_t)nt << 16);
+    }
+}
+
 struct Runner {
     mz_handle* h;
     hipStream_t s;
@@ -726,24 +750,7 @@ struct Runner {
         if (it == h->tile_tabs.end()) {
             std::vector<uint32_t> t;
             t.reserve(2 * ((size_t)a.mtiles * a.ntiles + pad));
-            const int tpi = a.tiles_x * a.tiles_y, gsz = a.gm * a.gn;
-            for (int L = 0; L < a.grid; ++L) {
-                const int group = L / gsz, within = L % gsz;
-                const int gi_n = group / a.groups_m, gi_m = group % a.groups_m;
-                const int mt = gi_m * a.gm + within / a.gn, nt = gi_n * a.gn + within % a.gn;
-                if (mt >= a.mtiles || nt >= a.ntiles) continue;
-                const int b = mt / tpi, trem = mt % tpi;
-                int tyi, txi;
-                if (!a.blk4) {
-                    tyi = trem / a.tiles_x; txi = trem % a.tiles_x;
-                } else {
-                    const int bsz = 4 * a.tiles_x, br = trem / bsz, rem = trem % bsz;
-                    const int rows = std::min(4, a.tiles_y - 4 * br);
-                    txi = rem / rows; tyi = 4 * br + rem % rows;
-                }
-                t.push_back((uint32_t)(tyi * th) | (uint32_t)(txi * tw) << 16);
-                t.push_back((uint32_t)b | (uint32_t)nt << 16);
-            }
+            tile_list(a, th, tw, t);
             const int n = (int)(t.size() / 2);
             t.resize(t.size() + 2 * (size_t)pad, 0u);
             void* d = nullptr;
@@ -1338,6 +1345,24 @@ extern "C" int mz_op_final(int dtype, const void* feat, const void* img, const f
 // ------------------------------------------------------------------------------------------------
 extern "C" const char* mz_last_error(void) { return g_err; }
 extern "C" const char* mz_debug_last_kernel(void) { return g_last_kernel; }
+
+// Host-only (no GPU): the tile list Runner::tile_table() uploads for a launch of B images of tiles_y x tiles_x tiles of th x tw pixels,
+// ntiles N tiles, walked in groups of gm x gn (blk4: block rows of four tile rows).  Writes at most cap entries of two words to out
+// and returns the number of tiles listed (tests/test_cabi_cpu.py checks that every tile appears exactly once).
+extern "C" int mz_debug_tile_list(int B, int tiles_y, int tiles_x, int ntiles, int gm, int gn, int blk4, int th, int tw, unsigned int* out, int cap) {
+    if (B < 1 || tiles_x < 1 || tiles_y < 1 || ntiles < 1 || gm < 1 || gn < 1 || th < 1 || tw < 1 || !out || cap < 0) return MZ_ERR_INVALID_ARGUMENT;
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.tiles_x = tiles_x; a.tiles_y = tiles_y; a.mtiles = B * tiles_x * tiles_y; a.ntiles = ntiles;
+    a.gm = gm < a.mtiles ? gm : a.mtiles; a.gn = gn < ntiles ? gn : ntiles; a.blk4 = blk4 ? 1 : 0;
+    a.groups_m = (a.mtiles + a.gm - 1) / a.gm;
+    a.grid = a.groups_m * ((ntiles + a.gn - 1) / a.gn) * a.gm * a.gn;
+    std::vector<uint32_t> t;
+    tile_list(a, th, tw, t);
+    const int n = (int)(t.size() / 2);
+    for (int i = 0; i < n && i < cap; ++i) { out[2 * i] = t[2 * i]; out[2 * i + 1] = t[2 * i + 1]; }
+    return n;
+}
 extern "C" const char* mz_version(void) { return "mewzoom_hip 0.1 (gfx950)"; }
 
 extern "C" double mz_flops_per_image(const mz_handle* h, int H, int W) {
