@@ -103,6 +103,53 @@ def test_conv3r_matches_oracle_and_conv3s(dt, case, monkeypatch):
     assert (pad_part(outs["r"], cout) == 0).all(), "pad channels must stay zero"
 
 
+RAG_CASES = [
+    # B, H, W, cout, persistent workgroups: Cin = 48 (two 32-channel chunks, the second with two real planes), conv1 + SiLU
+    (1, 8, 48, 96, 0),       # one tile
+    (1, 16, 144, 96, 8),     # six tiles on eight workgroups
+    (3, 40, 100, 96, 8),     # 45 tiles on 8 workgroups: both teams, several tiles each, ragged edges
+    (2, 13, 37, 192, 0),     # two N tiles, a tile larger than the image
+    (1, 27, 200, 80, 16),    # Cout = 80: planes of the N tile that do not exist
+    (2, 135, 240, 96, 0),    # a real level size on every CU
+]
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("case", RAG_CASES)
+def test_conv3r_ragged_cin48(dt, case, monkeypatch):
+    """conv3r_kernel<.., RAG>: Cin = 48.  The pieces of the second chunk's missing planes are issued out of range (zeros into LDS), the
+    weights are packed with K padded to 64.  Against the oracle (1 ulp), and bit for bit against conv3s_kernel with the same padded K
+    (MZ_KPAD_PCT=34 lets it take Cin = 48): same chunk / tap / 32-channel MFMA order."""
+    dtype = DTYPES[dt]
+    B, H, W, cout, wgs = case
+    cin = 48
+    x = q(rnd((B, cin, H, W), 41), dtype)
+    w = q(wrnd((cout, cin, 3, 3), 42), dtype)
+    xa = to_act(x, dtype)
+    outs = {}
+    for name, env in {"r": {}, "s": {"MZ_NO_R2": "1", "MZ_NO_Q": "1", "MZ_KPAD_PCT": "34"}}.items():
+        for k in ("MZ_NO_Q", "MZ_NO_R", "MZ_NO_R2", "MZ_KPAD_PCT", "MZ_PERSIST_WGS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        if wgs:
+            monkeypatch.setenv("MZ_PERSIST_WGS", str(wgs))
+        out = alloc_act(B, cout, H, W, dtype)
+        op_conv(dtype, 0, xa, None, w, 0.0, out, B, H, W, cin, cout, silu=1)
+        outs[name] = out
+        assert last_kernel() == ("conv3r_ragged" if name == "r" else "conv3s"), last_kernel()
+    want = F.silu(F.conv2d(x, w, padding=1))
+    assert_op_close(from_act(outs["r"], cout), want, dt, "conv3r ragged")
+    assert torch.equal(outs["r"], outs["s"]), "conv3r (ragged Cin) and conv3s (K padded) must agree bit for bit"
+    assert (pad_part(outs["r"], cout) == 0).all(), "pad channels must stay zero"
+    # without the activation the host keeps the layer off the ragged variant (it exists for conv1 + SiLU)
+    monkeypatch.delenv("MZ_NO_R2", raising=False); monkeypatch.delenv("MZ_NO_Q", raising=False); monkeypatch.delenv("MZ_KPAD_PCT", raising=False)
+    out = alloc_act(B, cout, H, W, dtype)
+    op_conv(dtype, 0, xa, None, w, 0.0, out, B, H, W, cin, cout, silu=0)
+    assert last_kernel() != "conv3r_ragged"
+    assert_op_close(from_act(out, cout), F.conv2d(x, w, padding=1), dt, "Cin = 48 without SiLU")
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("shape", [(2, 40, 70, 96, 384, 81, 140), (1, 30, 100, 96, 192, 60, 200), (1, 16, 48, 128, 96, 33, 97),
                                    # 8 x 40 tiles (W = 120, 80, 37): the straddling fragment's sub-pixel store

@@ -305,7 +305,11 @@ __device__ __forceinline__ void blend_pair_to(float& o0, float& o1, const float 
 
 // EPI: EPI_STORE (SILU: with the activation), EPI_D2S, EPI_FUSEDMIX (needs NSEG = 3).  SILU is a template parameter: a run-time
 // branch around the activation made hipcc copy every value twice more on its way through the epilogue.
-template <class TT, int NSEG, int EPI, bool SILU, int GEO = 0>
+// RAG: tiles of exactly TWO chunks whose second chunk lacks planes (Cin = 48: conv1 of the 48-channel models' level-1 block): the pieces of
+// the missing planes are issued with every lane out of range -- the hardware writes zeros into LDS, the step's piece count stays what the
+// closing vmcnt expects --, the weights are packed with K padded to 64.  A quarter of the MFMAs multiply zeros; the tile is bound by its
+// 18 SiLU entries in the helper role either way (three per step), which here run under the K loop instead of behind it.
+template <class TT, int NSEG, int EPI, bool SILU, int GEO = 0, bool RAG = false>
 __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     using namespace r3;
     using S = Seg<NSEG>;
@@ -316,10 +320,11 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     static_assert(!FUSE || GEO == 0, "the fused variant is built for the 8 x 48 tile");
     constexpr int B_SLOT = S::SLOT;
     static_assert(!FUSE || NSEG == 3, "the gate weights need the LDS that three weight segments leave free");
+    static_assert(!RAG || (NSEG == 3 && EPI == EPI_STORE && GEO == 0), "the ragged two-chunk variant: three steps per chunk, plain stores, 8 x 48 tiles");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int team = w >> 2, wq = w & 3;  // wq: SIMD = tile rows 2 wq, 2 wq + 1 (compute) = loader index
-    const int nchunks = a.nchunks16;       // 32-channel chunks, >= 3 (the host guards)
+    const int nchunks = a.nchunks16;       // 32-channel chunks, >= 3 (RAG: exactly 2; the host guards)
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
     // ---- tile walk: the host lists the launch's tiles in walk order (mz_host.cpp: tile_table(); a.grid entries of eight bytes, the
@@ -403,10 +408,15 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     // LDS-DMA, one 1-KiB piece at a time (the pieces of a step are interleaved with epilogue arithmetic: an LDS-DMA instruction
     // holds the issuing wave for ~50 cycles -- the CU's L1 -> LDS path --, which the VALU work between two pieces hides).
     // halo piece i (0..7) of this wave: entries [64 (wq + 4 i), + 64) of the image
-    auto halo_piece = [&](auto i_tag, const __amdgpu_buffer_rsrc_t rsrc, char* dst) __attribute__((always_inline)) {
+    // (rag: the image of a chunk that lacks planes -- RAG only --: the pieces of planes >= a.ragged_planes carry an out-of-range offset)
+    auto halo_piece = [&](auto i_tag, const __amdgpu_buffer_rsrc_t rsrc, char* dst, [[maybe_unused]] const bool rag = false) __attribute__((always_inline)) {
         constexpr int i = decltype(i_tag)::value;
+        uint32_t off = hoff[i & 1];
+        if constexpr (RAG) {
+            if (rag && (i >> 1) >= a.ragged_planes) off = 0xffffffffu;
+        }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + (wq + 4 * i) * 1024), 16,
-                                                 (int)hoff[i & 1], (int)((uint32_t)(i >> 1) * (uint32_t)plane_in), 0, 0);
+                                                 (int)off, (int)((uint32_t)(i >> 1) * (uint32_t)plane_in), 0, 0);
     };
     auto halo_rsrc = [&](int kc) __attribute__((always_inline)) {  // the four planes of chunk kc (all exist: Cin % 32 == 0)
         return __builtin_amdgcn_make_buffer_rsrc((void*)(img_l + 4LL * kc * plane_in), 0, (int)(uint32_t)(4 * plane_in), 0x00020000);
@@ -684,9 +694,10 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
             uint32_t h_off = (uint32_t)(us ^ 1) * (uint32_t)A_SLOT;
             asm volatile("" : "+s"(h_off));
             char* const h_dst = smem + h_off;
-            halo_piece(ic<0>{}, h_rsrc, h_dst); halo_piece(ic<1>{}, h_rsrc, h_dst); halo_piece(ic<2>{}, h_rsrc, h_dst);
-            halo_piece(ic<3>{}, h_rsrc, h_dst); halo_piece(ic<4>{}, h_rsrc, h_dst); halo_piece(ic<5>{}, h_rsrc, h_dst);
-            halo_piece(ic<6>{}, h_rsrc, h_dst); halo_piece(ic<7>{}, h_rsrc, h_dst);
+            const bool rag = RAG && !last && k + 2 == nchunks;  // the tile's last chunk is the ragged one
+            halo_piece(ic<0>{}, h_rsrc, h_dst, rag); halo_piece(ic<1>{}, h_rsrc, h_dst, rag); halo_piece(ic<2>{}, h_rsrc, h_dst, rag);
+            halo_piece(ic<3>{}, h_rsrc, h_dst, rag); halo_piece(ic<4>{}, h_rsrc, h_dst, rag); halo_piece(ic<5>{}, h_rsrc, h_dst, rag);
+            halo_piece(ic<6>{}, h_rsrc, h_dst, rag); halo_piece(ic<7>{}, h_rsrc, h_dst, rag);
         };
         if constexpr (sg == 0 && !HALO_LATE) {
             if (!last || okB) halo_image();
@@ -797,7 +808,11 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
             epi_setup();
             RS_FENCE();
             RS_LAP(27);
-            if constexpr (FUSE) {
+            if constexpr (RAG) {
+                // two chunks, six steps, three entries each
+                loader_chunk(ic<0>{}, ic<3>{}, ic<6>{}, ic<0>{}, 0);
+                loader_chunk(ic<9>{}, ic<3>{}, ic<6>{}, ic<1>{}, 1);
+            } else if constexpr (FUSE) {
                 // one pixel fragment per chunk: the tile has at least six chunks (C = 96: Cin = 192; the host guards)
                 fuse_chunk(ic<0>{}, ic<1>{}, ic<0>{}, 0);
                 fuse_chunk(ic<1>{}, ic<1>{}, ic<0>{}, 1);

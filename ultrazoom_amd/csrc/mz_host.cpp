@@ -75,6 +75,7 @@ struct Knobs {
     int q = 1;              // MZ_NO_Q=1: never use conv3q_kernel (one compute + one loader wave per SIMD, 8 x 48 tiles)
     int r = 1;              // MZ_NO_R=1: never use conv3r_kernel (conv3q's tile with role-alternating waves: epilogues under the next K loop)
     int geo40 = 1;          // MZ_NO_GEO40=1: conv3r_kernel keeps its 8 x 48 tiles where 8 x 40 tiles would pad fewer pixels
+    int r2 = 1;             // MZ_NO_R2=1: Cin = 48 -> 96-channel N tiles (conv1 of the 48-channel models' level-1 block) stays off conv3r_kernel's ragged variant
     int t = 1;              // MZ_NO_T=1: never use conv3t_kernel (the same structure for ONE N tile of <= 48 channels, 12 x 64 tiles)
 };
 static Knobs read_knobs() {
@@ -89,6 +90,7 @@ static Knobs read_knobs() {
     k.q = getenv("MZ_NO_Q") == nullptr;
     k.r = getenv("MZ_NO_R") == nullptr;
     k.t = getenv("MZ_NO_T") == nullptr;
+    k.r2 = getenv("MZ_NO_R2") == nullptr;
     k.geo40 = getenv("MZ_NO_GEO40") == nullptr;
     k.blk4 = getenv("MZ_NO_BLK4") == nullptr;
     if (const char* e = getenv("MZ_KPAD_PCT")) k.kpad_pct = atoi(e);
@@ -838,6 +840,28 @@ struct Runner {
             if (r) { r->kind = 0; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.gm * 1000 + a.gn; }
             g_last_kernel = t_fuse ? "conv3t_fused" : "conv3t";
             check(launch_conv3t(dtype, a, s), "conv3t launch");
+            prof_end(r);
+            return;
+        }
+        // conv3r_kernel's ragged variant: conv1 + SiLU with Cin = 48 (two 32-channel chunks, the second with two real planes) into 96-channel
+        // N tiles.  The kernel it replaces (conv3p_kernel: 32x32x16 MFMA, exact 16-channel chunks) sums in another order, so the choice
+        // depends on channel counts, dtype and knobs only -- never on H or W.
+        const bool use_r2 = knobs.r && knobs.r2 && use_s16 && !film_gamma && dtype != DT_F32 && c.nt == 3 && c.packed16 && epi == EPI_STORE && silu &&
+                            persist_wgs > 0 && c.nchunks16 == 2 && c.cp0 == 48 && (double)H * W * 64.0 < 4294967296.0 &&
+                            12.0 * H * W * 16.0 < 4294967296.0;
+        if (use_r2) {
+            a.tiles_x = (W + 47) / 48; a.tiles_y = (H + 7) / 8;
+            a.mtiles = B * a.tiles_x * a.tiles_y;
+            pick_order(a, c, px * c.cp0 * sz);
+            a.s16 = 1; a.wpk16 = c.packed16; a.nchunks16 = 2;
+            a.ragged_planes = (c.cp0 - 32) / 8;
+            tile_table(a, 8, 48);
+            if (rc) return;
+            ProfRec* r;
+            prof_begin(r, 2.0 * px * 9.0 * c.cin * c.cout, px * (c.cin + c.cout) * sz + 9.0 * c.cin * c.cout * sz, 1);
+            if (r) { r->kind = 0; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.gm * 1000 + a.gn; }
+            g_last_kernel = "conv3r_ragged";
+            check(launch_conv3r(dtype, a, s), "conv3r ragged launch");
             prof_end(r);
             return;
         }

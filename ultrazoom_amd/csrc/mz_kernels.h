@@ -75,6 +75,8 @@ struct ConvArgs {
     int nchunks16;     // 32-channel chunks
     const void* tile_tab;  // conv3r / conv3t: the launch's tiles in walk order, uint2 {y0 | x0 << 16, image | N tile << 16} each, padded with
                            // 4 * persist / 8 + 8 entries; a.grid = its length (mz_host.cpp: tile_table())
+    int ragged_planes; // conv3r_kernel<.., RAG>: 16-byte planes that exist in the LAST 32-channel chunk (1..3; Cin = 48: 2): the pieces of the
+                       // others are issued with every lane out of range (zeros into LDS); 0 = every chunk has its four planes
     int geo;           // conv3r_kernel: pixel-tile geometry, 0 = 8 x 48 (six pixel fragments per wave), 1 = 8 x 40 (five)
     const void* wmix16; // EPI_FUSEDMIX on the 16x16x32 kernel: gate weights packed [2*nt K-steps][2*nt][64 lanes][16 B]
     const float* film_gamma;  // EPI_STORE on conv3s_kernel only: per-image per-channel affine gamma * y + beta ahead of the SiLU
@@ -99,7 +101,8 @@ hipError_t init_kernels();  // raises the dynamic-LDS limits (per device)
 hipError_t launch_conv3q(int dtype, const ConvArgs& a, hipStream_t s);
 hipError_t init_conv3q();
 // conv3r_kernel (mz_conv3r.h): the same tile shape and K loop, but the two waves of every SIMD alternate between the compute
-// and the loader + epilogue role from tile to tile.  >= 3 chunks of 32 channels (odd counts included); EPI_STORE / EPI_D2S
+// and the loader + epilogue role from tile to tile.  >= 3 chunks of 32 channels (odd counts included; a.ragged_planes != 0: exactly
+// two, the second with a.ragged_planes real planes -- Cin = 48 --, EPI_STORE + SiLU only); EPI_STORE / EPI_D2S
 // (32-bit store offsets: 12 planes of the output, resp. one whole D2S target image, must stay below 4 GiB); EPI_FUSEDMIX: >= 6
 // chunks, a.wmix16 = gate weights packed with PackArgs::frag16 = 2, a.in1 / a.p1 = the block input.
 hipError_t launch_conv3r(int dtype, const ConvArgs& a, hipStream_t s);
