@@ -167,7 +167,7 @@ int mz_profile_read(mz_handle* h, double* conv_ms, double* conv_flops, double* c
 int mz_debug_read(unsigned long long* host_dst);
 
 /* Kernel family of the calling thread's most recent convolution / mix launch ("conv3r", "conv3r_8x40", "conv3r_fused", "conv3t",
- * "conv3t_fused", "conv3q", "conv3s", "conv3s_fused", "conv3p", "conv3w", "conv3w_fused", "conv_kernel", "mix16", "mix16b",
+ * "conv3t_fused", "conv3r_ragged", "conv3s", "conv3s_fused", "conv3p", "conv3w", "conv3w_fused", "conv_kernel", "mix16", "mix16b",
  * "conv_kernel_mix"): lets a test that compares two kernels assert that it really ran both.  No reference counterpart. */
 const char* mz_debug_last_kernel(void);
 

@@ -1,8 +1,8 @@
-"""conv3r_kernel (conv3q's 8 x 48 x 96-channel tile with role-alternating waves: a tile's epilogue runs under the next tile's
-K loop) against the oracle and against conv3s_kernel.  All three 16x16x32 kernels accumulate every output element in the
-same order (chunk, tap, 32-channel MFMA), so they must agree bit for bit.  conv3r is the default where it applies (96-channel
-N tiles, >= 3 chunks of 32 channels -- odd counts included --, no more padded pixels than the conv3s tiles); MZ_NO_R=1 leaves
-conv3q (even chunk counts) / conv3s."""
+"""conv3r_kernel (8 x 48 / 8 x 40 pixel x 96-channel tiles with role-alternating waves: a tile's epilogue runs under the next tile's
+K loop) against the oracle and against conv3s_kernel.  The 16x16x32 kernels accumulate every output element in the same order (chunk,
+tap, 32-channel MFMA), so they must agree bit for bit.  conv3r is the default where it applies (96-channel N tiles, >= 3 chunks of 32
+channels -- odd counts included --, no more padded pixels than the conv3s tiles; Cin = 48: its ragged two-chunk variant); MZ_NO_R=1
+leaves conv3s."""
 
 import pytest
 import torch
@@ -35,7 +35,7 @@ R_CASES = [
     (3, 40, 100, 96, 192, 1, 8),   # 45 pixel tiles x 2 N tiles on 8 workgroups: ~11 tiles per workgroup, weight switches, odd counts
     (2, 13, 37, 128, 96, 1, 0),    # ragged edges in both directions, four chunks
     (1, 70, 70, 192, 96, 0, 8),    # six chunks
-    (1, 20, 130, 112, 96, 0, 8),   # Cin = 112: the last chunk has two planes only -> the host must NOT pick conv3r (conv3q takes it)
+    (1, 20, 130, 112, 96, 0, 8),   # Cin = 112: the last chunk has two planes only -> the host must NOT pick conv3r
     (2, 9, 250, 160, 288, 1, 16),  # five chunks, three N tiles
     (1, 135, 240, 192, 96, 1, 0),  # the level-4 geometry of cfg3 (5 tiles per row, 17 tile rows)
     (1, 24, 50, 96, 80, 1, 8),     # Cout = 80: the N tile's last plane pair does not exist (range-checked stores)
@@ -61,7 +61,7 @@ def expected_r_kernel(H, W):
 
 
 def run(dtype, kind, x_act, w, out_shape, args, env, monkeypatch, wgs):
-    for k in ("MZ_NO_Q", "MZ_NO_R", "MZ_PERSIST_WGS"):
+    for k in ("MZ_NO_R", "MZ_PERSIST_WGS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -81,9 +81,9 @@ def test_conv3r_matches_oracle_and_conv3s(dt, case, monkeypatch):
     w = q(wrnd((cout, cin, 3, 3), 32), dtype)
     xa = to_act(x, dtype)
     outs = {}
-    for name, env in {"r": {}, "s": {"MZ_NO_Q": "1", "MZ_NO_R": "1"}}.items():
+    for name, env in {"r": {}, "s": {"MZ_NO_R": "1"}}.items():
         out = alloc_act(B, cout, H, W, dtype)
-        for k in ("MZ_NO_Q", "MZ_NO_R", "MZ_PERSIST_WGS"):
+        for k in ("MZ_NO_R", "MZ_PERSIST_WGS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -127,8 +127,8 @@ def test_conv3r_ragged_cin48(dt, case, monkeypatch):
     w = q(wrnd((cout, cin, 3, 3), 42), dtype)
     xa = to_act(x, dtype)
     outs = {}
-    for name, env in {"r": {}, "s": {"MZ_NO_R2": "1", "MZ_NO_Q": "1", "MZ_KPAD_PCT": "34"}}.items():
-        for k in ("MZ_NO_Q", "MZ_NO_R", "MZ_NO_R2", "MZ_KPAD_PCT", "MZ_PERSIST_WGS"):
+    for name, env in {"r": {}, "s": {"MZ_NO_R2": "1", "MZ_KPAD_PCT": "34"}}.items():
+        for k in ("MZ_NO_R", "MZ_NO_R2", "MZ_KPAD_PCT", "MZ_PERSIST_WGS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -143,7 +143,7 @@ def test_conv3r_ragged_cin48(dt, case, monkeypatch):
     assert torch.equal(outs["r"], outs["s"]), "conv3r (ragged Cin) and conv3s (K padded) must agree bit for bit"
     assert (pad_part(outs["r"], cout) == 0).all(), "pad channels must stay zero"
     # without the activation the host keeps the layer off the ragged variant (it exists for conv1 + SiLU)
-    monkeypatch.delenv("MZ_NO_R2", raising=False); monkeypatch.delenv("MZ_NO_Q", raising=False); monkeypatch.delenv("MZ_KPAD_PCT", raising=False)
+    monkeypatch.delenv("MZ_NO_R2", raising=False); monkeypatch.delenv("MZ_KPAD_PCT", raising=False)
     out = alloc_act(B, cout, H, W, dtype)
     op_conv(dtype, 0, xa, None, w, 0.0, out, B, H, W, cin, cout, silu=0)
     assert last_kernel() != "conv3r_ragged"
@@ -162,8 +162,8 @@ def test_conv3r_subpixel(dt, shape, monkeypatch):
     w = q(wrnd((cout, cin, 3, 3), 34), dtype)
     xa = to_act(x, dtype)
     outs = {}
-    for name, env in {"r": {}, "s": {"MZ_NO_Q": "1", "MZ_NO_R": "1"}}.items():
-        for k in ("MZ_NO_Q", "MZ_NO_R"):
+    for name, env in {"r": {}, "s": {"MZ_NO_R": "1"}}.items():
+        for k in ("MZ_NO_R",):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -269,9 +269,9 @@ def test_conv3r_shape_sweep_equals_conv3s(case, monkeypatch):
     w = q(wrnd((cout, cin, 3, 3), 42), dtype)
     xa = to_act(x, dtype)
     outs = {}
-    for name, env in {"r": {}, "s": {"MZ_NO_Q": "1", "MZ_NO_R": "1"}}.items():
+    for name, env in {"r": {}, "s": {"MZ_NO_R": "1"}}.items():
         out = alloc_act(B, cout, H, W, dtype)
-        for k in ("MZ_NO_Q", "MZ_NO_R", "MZ_PERSIST_WGS"):
+        for k in ("MZ_NO_R", "MZ_PERSIST_WGS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -21,7 +21,7 @@ LISTINGS = {}
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 # kernels the execution plans of the 16-bit modes use (name prefix of the demangled-ish symbol)
-HOT = ("conv3r_kernel", "conv3t_kernel", "conv3q_kernel", "conv3s_kernel", "mix16_kernel", "mix16b_kernel", "conv3w_kernel")
+HOT = ("conv3r_kernel", "conv3t_kernel", "conv3s_kernel", "mix16_kernel", "mix16b_kernel", "conv3w_kernel")
 # Instantiations that are NOT on the default plans of the 16-bit modes and are known to spill (fallbacks / A-B knobs):
 #   conv3s_kernel<T, NT = 3, *, FUSE>: the C = 65..96 fused conv2 + mix; conv3r_kernel's fused variant takes it wherever the tile has six
 #                                      or more chunks (hidden_ratio >= 2), so this one only runs for hidden_ratio 1 or MZ_NO_R=1
@@ -54,7 +54,7 @@ def resource_usage(src: str):
 def test_hot_kernels_use_no_scratch():
     from concurrent.futures import ThreadPoolExecutor
 
-    sources = ["mz_kernels.hip", "mz_conv3r.hip", "mz_conv3q.hip", "mz_conv3t.hip"]
+    sources = ["mz_kernels.hip", "mz_conv3r.hip", "mz_conv3t.hip"]
     with ThreadPoolExecutor(max_workers=4) as ex:  # four hipcc processes side by side: ~2 minutes in total
         usages = dict(zip(sources, ex.map(resource_usage, sources)))
     for src, usage in usages.items():
@@ -63,7 +63,7 @@ def test_hot_kernels_use_no_scratch():
         bad = {k: v for k, v in hot.items() if v.get("ScratchSize", 0) != 0 or v.get("VGPRs Spill", 0) != 0}
         assert not bad, "kernels with scratch memory / spilled VGPRs: " + ", ".join(f"{k}: {v}" for k, v in bad.items())
         for k, v in hot.items():
-            if "conv3r_kernel" in k or "conv3q_kernel" in k or "conv3t_kernel" in k:
+            if "conv3r_kernel" in k or "conv3t_kernel" in k:
                 assert v.get("Occupancy", v.get("Occupancy [waves/SIMD]", 2)) >= 2, f"{k}: two waves per SIMD are the design"
     # The same listings, scanned for the store-data hazard of gfx950: a 12- / 16-byte store (buffer or global, any offset form) whose data
     # registers are overwritten within two wait states -- hipcc inserts none behind a buffer store with an SGPR offset and one behind the

@@ -291,7 +291,7 @@ FUZZ_CONFIGS = [
     (2, (80, 48, 24, 16), (2, 2, 2, 2), 2, (1, 48, 64)),
     (4, (48, 24, 32, 64), (2, 2, 2, 2), 4, (1, 24, 40)),
     (2, (48, 96, 16, 32), (2, 3, 2, 2), 1, (3, 17, 29)),
-    (2, (32, 64, 192, 192), (2, 2, 2, 2), 2, (2, 64, 104)),  # C = 192 levels: conv3q_kernel (96-channel N tiles, even chunk counts)
+    (2, (32, 64, 192, 192), (2, 2, 2, 2), 2, (2, 64, 104)),  # C = 192 levels: conv3r_kernel (96-channel N tiles)
 ]
 
 
@@ -353,10 +353,10 @@ def test_kernel_variants_agree(dtype, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_conv3q_and_tile_walk_knobs_leave_the_bits_unchanged(dtype, monkeypatch):
-    """conv3r_kernel, conv3q_kernel and conv3s_kernel accumulate in the same order, and the block-row tile walk only changes which
-    workgroup computes which tile: a model whose deep levels run conv3r must produce the SAME BITS with MZ_NO_R=1 (conv3q / conv3s),
-    with MZ_NO_Q=1 MZ_NO_R=1 (conv3s everywhere) and with MZ_NO_BLK4=1
+def test_conv3r_and_tile_walk_knobs_leave_the_bits_unchanged(dtype, monkeypatch):
+    """conv3r_kernel and conv3s_kernel accumulate in the same order, and the block-row tile walk only changes which
+    workgroup computes which tile: a model whose deep levels run conv3r must produce the SAME BITS with MZ_NO_R=1 (conv3s everywhere)
+    and with MZ_NO_BLK4=1
     (knobs are read when the engine is created, hence refresh_weights())."""
     names = ("primary", "secondary", "tertiary", "quaternary")
     cfg = {"upscale_ratio": 2, "hidden_ratio": 2, "num_deg_features": 3}
@@ -367,9 +367,9 @@ def test_conv3q_and_tile_walk_knobs_leave_the_bits_unchanged(dtype, monkeypatch)
     x = synth_image(3, 200, 392, seed=6).to("cuda", dtype)   # levels 3 / 4 at 50 x 98 and 25 x 49: several ragged 8 x 48 tiles
     m = build(cfg, sd, dtype)
     outs = {}
-    for name, env in {"default": {}, "no_r": {"MZ_NO_R": "1"}, "no_q_no_r": {"MZ_NO_Q": "1", "MZ_NO_R": "1"}, "no_blk4": {"MZ_NO_BLK4": "1"},
+    for name, env in {"default": {}, "no_r": {"MZ_NO_R": "1"}, "no_blk4": {"MZ_NO_BLK4": "1"},
                       "few_wgs": {"MZ_PERSIST_WGS": "8"}, "few_wgs_no_r": {"MZ_PERSIST_WGS": "8", "MZ_NO_R": "1"}}.items():
-        for k in ("MZ_NO_Q", "MZ_NO_R", "MZ_NO_BLK4", "MZ_PERSIST_WGS"):
+        for k in ("MZ_NO_R", "MZ_NO_BLK4", "MZ_PERSIST_WGS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -380,4 +380,4 @@ def test_conv3q_and_tile_walk_knobs_leave_the_bits_unchanged(dtype, monkeypatch)
     with torch.inference_mode():
         want = oracle.upscale(cfg, sd, x.float().cpu())
         matched = oracle.upscale(cfg, sd, x.float().cpu(), storage=dtype)
-    lowp_gate_vs_matched(outs["default"], want, matched, f"conv3q model {TAG[dtype]}")
+    lowp_gate_vs_matched(outs["default"], want, matched, f"conv3r model {TAG[dtype]}")

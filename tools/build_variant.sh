@@ -6,7 +6,7 @@ tag=$1; shift
 here="$(cd "$(dirname "$0")/../ultrazoom_amd/csrc" && pwd)"
 mkdir -p "$here/build"
 /opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -c "$here/mz_host.cpp" -o "$here/build/mz_host.o"
-units=(mz_kernels mz_conv3q mz_conv3r mz_conv3t mz_probe)
+units=(mz_kernels mz_conv3r mz_conv3t mz_probe)
 pids=()
 for u in "${units[@]}"; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c "$here/$u.hip" -o "$here/build/${u}_$tag.o" &

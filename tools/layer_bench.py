@@ -12,7 +12,7 @@ from ultrazoom_amd import MewZoom
 from ultrazoom_amd.synth import synth_image, synth_state_dict
 
 VARIANTS = {"base": {"MZ_NO_R": "1"}, "r": {}}
-if os.environ.get("LAYER_BENCH_VARIANTS"):   # e.g. LAYER_BENCH_VARIANTS='{"a": {}, "b": {"MZ_NO_Q": "1"}}'
+if os.environ.get("LAYER_BENCH_VARIANTS"):   # e.g. LAYER_BENCH_VARIANTS='{"a": {}, "b": {"MZ_NO_GEO40": "1"}}'
     import json
     VARIANTS = json.loads(os.environ["LAYER_BENCH_VARIANTS"])
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3

@@ -9,7 +9,7 @@ for f in glob.glob(os.path.join(root, "*", "*", "*_counter_collection.csv")):
     seen = set()
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        tags = {"conv3t_kernel": "T:", "conv3r_kernel": "R:", "conv3q_kernel": "Q:", "conv3s_kernel": "S16:", "conv3p_kernel": "P:", "conv3w_kernel": "W:", "mix16b_kernel": "MIX16B:", "mix16_kernel": "MIX16:", "conv_kernel": ""}
+        tags = {"conv3t_kernel": "T:", "conv3r_kernel": "R:", "conv3s_kernel": "S16:", "conv3p_kernel": "P:", "conv3w_kernel": "W:", "mix16b_kernel": "MIX16B:", "mix16_kernel": "MIX16:", "conv_kernel": ""}
         tag = next((t for k, t in tags.items() if k in name), None)
         if tag is None: continue
         short = tag + name.split("_kernel<")[1].split(">")[0].replace("mz::", "")

@@ -12,7 +12,7 @@ tot = collections.defaultdict(float); n = collections.defaultdict(set)
 for cname, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     for f in glob.glob(os.path.join(root, sub, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            if not any(k in r["Kernel_Name"] for k in ("conv3s_kernel", "conv3p_kernel", "conv3w_kernel", "conv3q_kernel", "conv3r_kernel", "conv3t_kernel")) or r["Counter_Name"] != cname: continue
+            if not any(k in r["Kernel_Name"] for k in ("conv3s_kernel", "conv3p_kernel", "conv3w_kernel", "conv3r_kernel", "conv3t_kernel")) or r["Counter_Name"] != cname: continue
             tot[cname] += float(r["Counter_Value"]); n[cname].add(r["Dispatch_Id"])
 launches = len(n["FETCH_SIZE"]) or 1
 fetch = 2.0 * tot["FETCH_SIZE"] * 1024 / launches

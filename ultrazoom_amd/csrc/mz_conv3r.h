@@ -1,15 +1,16 @@
 // conv3r_kernel ("relay"): 3x3 convolution (pad 1, stride 1) on v_mfma_f32_16x16x32_{bf16,f16} whose two waves per SIMD
 // ALTERNATE roles from tile to tile, so that a tile's store / SiLU / mix epilogue runs under the NEXT tile's K loop.
 //
-// Why (DESIGN.md section 5, round-2 stamps): in conv3q_kernel every SIMD holds one compute wave (96 px x 96 channels, 144
+// Why (EXPERIMENTS.md section 5, round-2 stamps): in round 2's conv3q_kernel (retired in round 4; history up to commit 40ea7e4) every SIMD
+// held one compute wave (96 px x 96 channels, 144
 // accumulator registers) and one loader wave whose 253 registers sit idle.  A tile of the Cin = 96 full-resolution layers is
 // only 3 - 6 K chunks long, and its epilogue (3.9 - 7.4 k cycles, store-path and SiLU bound) runs with the matrix pipe idle:
 // those layers reach 0.46 of the MFMA peak where the deep layers reach 0.65.
 //
 // Here the workgroup is two TEAMS of four waves (team X = waves 0..3, team Y = waves 4..7; waves w and w + 4 share a SIMD).
-// Tile i of the workgroup is computed by team i & 1.  While one team runs the K loop of tile i (exactly conv3q's compute
+// Tile i of the workgroup is computed by team i & 1.  While one team runs the K loop of tile i (exactly that kernel's compute
 // wave: same tile shape, same fragment stream, same summation order => bit-identical sums), the other team
-//   * issues all LDS-DMA of those half-steps (the loader role of conv3q: halo image one chunk ahead, weight segments two
+//   * issues all LDS-DMA of those half-steps (its loader role: halo image one chunk ahead, weight segments two
 //     steps ahead -- near the end of the tile these already belong to tile i + 1),
 //   * finishes ITS OWN previous tile i - 1 out of its accumulators: SiLU / pack / stores, a few 16-byte entries per step,
 //     placed behind the step's DMA issue,
@@ -34,7 +35,7 @@
 //     the hardware's range check does not see scalar offsets, so every chunk must have its four planes; the host guards);
 //   * the lane index behind a step's weight pieces is worked out once per step, the piece index goes into the scalar base.
 //
-// NSEG = weight segments (= barriers) per 32-channel chunk: 2 (14 + 13 groups, 3 x 28 KB weight slots, as conv3q) or 3
+// NSEG = weight segments (= barriers) per 32-channel chunk: 2 (14 + 13 groups, 3 x 28 KB weight slots) or 3
 // (9 + 9 + 9 groups = tap rows, 3 x 18 KB slots).  Shipped: 3 everywhere (mz_conv3r.hip).  With three steps per chunk the compute
 // role first touches the NEXT halo image in the chunk's third step, so the helper issues that image BEHIND the first step's weight
 // pieces and its closing wait leaves the eight pieces in flight (HALO_LATE in loader_step()): the lines have two steps to come out of
@@ -859,7 +860,7 @@ __global__ __launch_bounds__(512) void conv3r_kernel(const ConvArgs a) {
     };
 
     // ------------------------------------------------------------------------------------------------
-    // compute role: the K loop of tile tA (conv3q_kernel's compute wave)
+    // compute role: the K loop of tile tA
     // ------------------------------------------------------------------------------------------------
     auto compute_phase = [&]() __attribute__((always_inline)) {
         const int lane_ = lane_now();

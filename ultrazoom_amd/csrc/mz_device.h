@@ -1,4 +1,4 @@
-// Device-side building blocks shared by the kernel translation units (mz_kernels.hip, mz_conv3q.hip): element types,
+// Device-side building blocks shared by the kernel translation units (mz_kernels.hip, mz_conv3r.hip, mz_conv3t.hip): element types,
 // conversions, MFMA wrappers, LDS-DMA / LDS fragment-read primitives, the XCD-aware tile walk.
 #pragma once
 #include "mz_kernels.h"

@@ -72,8 +72,7 @@ struct Knobs {
     int persist = -1;       // MZ_NO_PERSIST=1 -> 0 (one workgroup per tile); MZ_PERSIST_WGS=n -> n; -1 = one per CU
     int kpad_pct = 12;      // MZ_KPAD_PCT=n: the 16x16x32 kernels take Cin whose padding to whole 32-channel chunks is <= n %
     int blk4 = 1;           // MZ_NO_BLK4=1: row-major tile walk inside an image (A/B of the L2 sharing of vertical halos)
-    int q = 1;              // MZ_NO_Q=1: never use conv3q_kernel (one compute + one loader wave per SIMD, 8 x 48 tiles)
-    int r = 1;              // MZ_NO_R=1: never use conv3r_kernel (conv3q's tile with role-alternating waves: epilogues under the next K loop)
+    int r = 1;              // MZ_NO_R=1: never use conv3r_kernel (96-channel N tiles, 8 x 48 / 8 x 40 pixel tiles, role-alternating waves: epilogues under the next K loop)
     int geo40 = 1;          // MZ_NO_GEO40=1: conv3r_kernel keeps its 8 x 48 tiles where 8 x 40 tiles would pad fewer pixels
     int r2 = 1;             // MZ_NO_R2=1: Cin = 48 -> 96-channel N tiles (conv1 of the 48-channel models' level-1 block) stays off conv3r_kernel's ragged variant
     int t = 1;              // MZ_NO_T=1: never use conv3t_kernel (the same structure for ONE N tile of <= 48 channels, 12 x 64 tiles)
@@ -87,7 +86,6 @@ static Knobs read_knobs() {
     k.fuse16 = getenv("MZ_NO_FUSE16") == nullptr;
     k.mix16 = getenv("MZ_NO_MIX16") == nullptr;
     k.mix16b = getenv("MZ_NO_MIX16B") == nullptr;
-    k.q = getenv("MZ_NO_Q") == nullptr;
     k.r = getenv("MZ_NO_R") == nullptr;
     k.t = getenv("MZ_NO_T") == nullptr;
     k.r2 = getenv("MZ_NO_R2") == nullptr;
@@ -728,7 +726,7 @@ struct Runner {
         a.inv_tpi = a.tiles_x > 0 ? 1.0f / (float)(a.tiles_x * a.tiles_y) : 1.0f;
         a.inv_tiles_x = a.tiles_x > 0 ? 1.0f / (float)a.tiles_x : 1.0f;
         a.inv_bsz = a.tiles_x > 0 ? 1.0f / (float)(4 * a.tiles_x) : 1.0f;
-        a.blk4 = knobs.blk4 && a.tiles_x > 0 && 4 * a.tiles_x < 65536 ? 1 : 0;  // read by conv3s_kernel / conv3q_kernel only
+        a.blk4 = knobs.blk4 && a.tiles_x > 0 && 4 * a.tiles_x < 65536 ? 1 : 0;  // the tile walk inside an image: conv3s_kernel, and the tile lists of conv3r / conv3t
         auto magic = [](long long d) { return d <= 1 ? 0xffffffffu : (uint32_t)(4294967296ULL / (unsigned long long)d); };
         a.mg_gsz = magic((long long)a.gm * a.gn); a.mg_groups_m = magic(a.groups_m); a.mg_gn = magic(a.gn);
         a.mg_tpi = magic(a.tiles_x > 0 ? (long long)a.tiles_x * a.tiles_y : 1); a.mg_tiles_x = magic(a.tiles_x > 0 ? a.tiles_x : 1);
@@ -812,10 +810,8 @@ struct Runner {
         }
         const double sz = dtype_size(dtype);
         const double px = (double)B * H * W;
-        // conv3q_kernel: one 512-register wave per SIMD, 8 x 48 pixel tiles, 96-channel N tiles
-        // (measured on the cfg3 shapes, tools/layer_bench.py: equal to conv3s_kernel where both tile shapes fit the image, 8 - 12 %
-        // faster on the 240-pixel-wide level, whose rows 48-pixel tiles cover exactly; it takes even chunk counts only)
-        bool q_common = use_s16 && !film_gamma && dtype != DT_F32 && c.nt == 3 && c.packed16 && (epi == EPI_STORE || epi == EPI_D2S) &&
+        // what conv3r_kernel's plain variants need in common: 16-bit type, 96-channel N tiles, the 16x16x32 packing, K padding within the knob
+        const bool r_common = use_s16 && !film_gamma && dtype != DT_F32 && c.nt == 3 && c.packed16 && (epi == EPI_STORE || epi == EPI_D2S) &&
                         persist_wgs > 0 && c.nchunks16 * 32 * 100 <= c.cp0 * (100 + knobs.kpad_pct) &&
                         (double)H * W * 64.0 < 4294967296.0;
         // conv3t_kernel: ONE N tile of 33..48 channels (the level-1 block of the 48-channel models), whole 32-channel chunks, three or six
@@ -865,7 +861,7 @@ struct Runner {
             prof_end(r);
             return;
         }
-        // padded pixels of conv3q / conv3r's 8 x 48 tiles -- and of conv3r's second geometry, 8 x 40 (five pixel fragments per wave: widths
+        // padded pixels of conv3r's 8 x 48 tiles -- and of its second geometry, 8 x 40 (five pixel fragments per wave: widths
         // like 120 that 48 does not divide) -- against the better of the 8 x 64 / 16 x 32 tiles.  (All plain variants accumulate in the same
         // order whatever the tile shape: bit-identical, so this choice may depend on H and W.)
         const long long rows8 = (long long)((H + 7) / 8 * 8);
@@ -873,13 +869,12 @@ struct Runner {
         const long long pads = (long long)a.tiles_y * th * a.tiles_x * tw;
         // conv3r_kernel: any chunk count >= 3 of four whole planes (its halo loads carry the plane in the scalar offset, which the
         // hardware's range check does not cover); its stores carry 32-bit offsets inside 12 output planes / one D2S target image
-        const bool r_ok = knobs.r && q_common && c.nchunks16 >= 3 && a.p0 % 4 == 0 &&
+        const bool r_ok = knobs.r && r_common && c.nchunks16 >= 3 && a.p0 % 4 == 0 &&
                           (epi == EPI_D2S ? (double)(c.cq_p * dtype_size(dtype) / 16) * Hout * Wout * 16.0 < 4294967296.0
                                           : 12.0 * H * W * 16.0 < 4294967296.0);
         const int geo = (r_ok && knobs.geo40 && pad40 < pad48) ? 1 : 0;
         const int tw_r = geo ? 40 : 48;
         const bool use_r = r_ok && (geo ? pad40 : pad48) <= pads;
-        const bool use_q = use_r || (knobs.q && q_common && pad48 <= pads && c.nchunks16 % 2 == 0);
         // ... and its fused variant (conv2 + AdaptiveResidualMix, C = 96): six or more chunks (one pixel fragment's gate GEMM and
         // blend per chunk), the gate weights packed in accumulator-row order, x and out within 32-bit offsets
         bool use_rf = knobs.r && knobs.fuse16 && epi == EPI_FUSEDMIX && use_s16 && dtype != DT_F32 && c.nt == 3 && c.ntiles == 1 && c.packed16 &&
@@ -906,26 +901,19 @@ struct Runner {
             prof_end(r);
             return;
         }
-        if (use_q) {
-            a.geo = use_r ? geo : 0;
-            const int tw_q = use_r ? tw_r : 48;  // (conv3q_kernel knows the 8 x 48 tile only)
-            a.tiles_x = (W + tw_q - 1) / tw_q; a.tiles_y = (H + 7) / 8;
+        if (use_r) {
+            a.geo = geo;
+            a.tiles_x = (W + tw_r - 1) / tw_r; a.tiles_y = (H + 7) / 8;
             a.mtiles = B * a.tiles_x * a.tiles_y;
             pick_order(a, c, px * c.cp0 * sz);
             a.s16 = 1; a.wpk16 = c.packed16; a.nchunks16 = c.nchunks16;
-            if (use_r) {
-                tile_table(a, 8, tw_q);
-                if (rc) return;
-            } else {
-                const int need = (a.grid + 7) / 8 * 8;
-                a.persist = need < persist_wgs ? need : persist_wgs;
-            }
+            tile_table(a, 8, tw_r);
+            if (rc) return;
             ProfRec* r;
             prof_begin(r, 2.0 * px * 9.0 * c.cin * c.cout, px * (c.cin + c.cout) * sz + 9.0 * c.cin * c.cout * sz, 1);
             if (r) { r->kind = 0; r->B = B; r->H = H; r->W = W; r->cin = c.cin; r->cout = c.cout; r->nt = c.nt; r->ntiles = a.ntiles; r->mtiles = a.mtiles; r->n_fast = a.gm * 1000 + a.gn; }
-            g_last_kernel = use_r ? (a.geo ? "conv3r_8x40" : "conv3r") : "conv3q";
-            if (use_r) check(launch_conv3r(dtype, a, s), "conv3r launch");
-            else check(launch_conv3q(dtype, a, s), "conv3q launch");
+            g_last_kernel = a.geo ? "conv3r_8x40" : "conv3r";
+            check(launch_conv3r(dtype, a, s), "conv3r launch");
             prof_end(r);
             return;
         }

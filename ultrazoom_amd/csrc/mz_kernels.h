@@ -55,7 +55,7 @@ struct ConvArgs {
     int grid;          // workgroups launched: whole groups, >= mtiles * ntiles
     int groups_m;      // ceil(mtiles / gm)
     float inv_gsz, inv_groups_m, inv_gn, inv_tpi, inv_tiles_x;  // 1.0f / divisor for fdiv() (all dividends < 2^24)
-    int blk4;          // conv3s / conv3q: tiles of an image are walked in block rows of four tile rows (tile_rc(), mz_device.h)
+    int blk4;          // conv3s, the tile lists of conv3r / conv3t: tiles of an image are walked in block rows of four tile rows (tile_rc(), mz_device.h)
     float inv_bsz;     // 1.0f / (4 * tiles_x)
     // conv3r_kernel: the same divisors as floor(2^32 / d) for sdiv() (scalar-unit division, mz_device.h)
     uint32_t mg_gsz, mg_groups_m, mg_gn, mg_tpi, mg_tiles_x, mg_bsz;
@@ -96,11 +96,8 @@ hipError_t launch_mix16(int dtype, const ConvArgs& a, hipStream_t s);
 // order); the gate matrix stays in LDS, every wave walks its own 32-pixel units
 hipError_t launch_mix16b(int dtype, const ConvArgs& a, hipStream_t s, int workgroups);  // persistent: at most `workgroups` (one per CU)
 hipError_t init_kernels();  // raises the dynamic-LDS limits (per device)
-// conv3q_kernel (mz_conv3q.hip): 3x3 convolution, 16-bit types, 96-channel N tiles (NT = 3), 8 x 48 pixel tiles, one
-// 512-register wave per SIMD.  a.persist workgroups of 256 threads; a.wpk16 / a.nchunks16 as for conv3s_kernel.
-hipError_t launch_conv3q(int dtype, const ConvArgs& a, hipStream_t s);
-hipError_t init_conv3q();
-// conv3r_kernel (mz_conv3r.h): the same tile shape and K loop, but the two waves of every SIMD alternate between the compute
+// conv3r_kernel (mz_conv3r.h): 3x3 convolution, 16-bit types, 96-channel N tiles (NT = 3), 8 x 48 / 8 x 40 pixel tiles, a.persist workgroups of
+// 512 threads; a.wpk16 / a.nchunks16 as for conv3s_kernel.  The two waves of every SIMD alternate between the compute
 // and the loader + epilogue role from tile to tile.  >= 3 chunks of 32 channels (odd counts included; a.ragged_planes != 0: exactly
 // two, the second with a.ragged_planes real planes -- Cin = 48 --, EPI_STORE + SiLU only); EPI_STORE / EPI_D2S
 // (32-bit store offsets: 12 planes of the output, resp. one whole D2S target image, must stay below 4 GiB); EPI_FUSEDMIX: >= 6

@@ -2139,7 +2139,7 @@ hipError_t init_kernels() {
     if ((e = set_lds_all<TF32>()) != hipSuccess) return e;
     if ((e = set_lds_all<TBF16>()) != hipSuccess) return e;
     if ((e = set_lds_all<TF16>()) != hipSuccess) return e;
-    return init_conv3q();
+    return hipSuccess;
 }
 
 // ================================================================================================
