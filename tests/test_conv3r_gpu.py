@@ -47,6 +47,8 @@ R_CASES = [
     (3, 23, 117, 96, 96, 1, 8),    # ragged in both directions; three chunks: 15 entries as 3 + 3, 3 + 3, 3 + 0
     (1, 30, 200, 192, 288, 0, 16), # six chunks (1 + 2 entries per chunk over five of them), three N tiles
     (1, 9, 79, 160, 96, 1, 8),     # five chunks
+    (2, 50, 190, 96, 192, 1, 24),  # 56 x 2 tiles on 24 workgroups (three per XCD): uneven shares of the tile list, 4 - 5 tiles per workgroup
+    (1, 33, 97, 192, 96, 0, 40),   # 15 tiles on 40 workgroups: most workgroups get none, some XCDs two
 ]
 
 

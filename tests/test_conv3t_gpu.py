@@ -54,6 +54,7 @@ T_CASES = [
     (2, 25, 65, 96, 33, 0, 16),    # Cout = 33
     (1, 36, 64, 128, 48, 1, 8),    # four chunks: the host must NOT pick conv3t (conv3s takes it); both settings agree
     (1, 135, 240, 96, 48, 1, 0),   # 12 x 4 tiles, rows 135 = 11 tiles + 3 rows
+    (2, 50, 190, 96, 48, 1, 24),   # 30 tiles on 24 workgroups (three per XCD): uneven shares of the tile list
 ]
 
 
