@@ -75,6 +75,7 @@ struct Knobs {
     int r = 1;              // MZ_NO_R=1: never use conv3r_kernel (96-channel N tiles, 8 x 48 / 8 x 40 pixel tiles, role-alternating waves: epilogues under the next K loop)
     int geo40 = 1;          // MZ_NO_GEO40=1: conv3r_kernel keeps its 8 x 48 tiles where 8 x 40 tiles would pad fewer pixels
     int r2 = 1;             // MZ_NO_R2=1: Cin = 48 -> 96-channel N tiles (conv1 of the 48-channel models' level-1 block) stays off conv3r_kernel's ragged variant
+    int head256 = 1;        // MZ_NO_HEAD256=1: the image head (EPI_FINAL) stays on the 512-pixel per-tile kernel instead of the 256-pixel one
     int t = 1;              // MZ_NO_T=1: never use conv3t_kernel (the same structure for ONE N tile of <= 48 channels, 12 x 64 tiles)
 };
 static Knobs read_knobs() {
@@ -88,6 +89,7 @@ static Knobs read_knobs() {
     k.mix16b = getenv("MZ_NO_MIX16B") == nullptr;
     k.r = getenv("MZ_NO_R") == nullptr;
     k.t = getenv("MZ_NO_T") == nullptr;
+    k.head256 = getenv("MZ_NO_HEAD256") == nullptr;
     k.r2 = getenv("MZ_NO_R2") == nullptr;
     k.geo40 = getenv("MZ_NO_GEO40") == nullptr;
     k.blk4 = getenv("MZ_NO_BLK4") == nullptr;
@@ -784,6 +786,11 @@ struct Runner {
             if (waste8 <= waste16) { mode = MODE_C3W8; th = 8; tw = 64; }
             else { mode = MODE_C3W16; th = 16; tw = 32; }
         }
+        // The image head (12 output channels + PixelShuffle + bicubic skip + clamp) is a per-tile kernel whose load, K loop and long
+        // epilogue run one after the other: on 512-pixel tiles (183 KB of LDS) a CU holds ONE workgroup and nothing overlaps; on the
+        // 256-pixel kernel several fit and one tile's epilogue runs under another's loads (2160 x 3840, Cin = 96: 2.34 -> 1.60 ms per 3
+        // images).  Chosen by dtype and knobs only, never by the image size.
+        if (epi == EPI_FINAL && knobs.head256 && dtype != DT_F32) { mode = MODE_CONV3; th = 8; tw = 32; }
         a.tiles_x = (W + tw - 1) / tw; a.tiles_y = (H + th - 1) / th;
         a.mtiles = B * a.tiles_x * a.tiles_y;
         a.epi = epi; a.silu = silu;
