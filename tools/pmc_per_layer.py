@@ -6,7 +6,9 @@ FETCH_SIZE is doubled (gfx950 counts 128-byte requests as 64 bytes, MI355X_MICRO
 import csv, sys, collections
 KERNELS = ("conv3s_kernel", "conv3p_kernel", "conv3w_kernel", "conv3r_kernel", "conv3t_kernel")
 def counters(path, name):
-    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == name and any(k in r["Kernel_Name"] for k in KERNELS)]
+    def is3(n):  # the persistent 3x3 kernels, and conv_kernel in its CONV3 mode (template argument MODE = 0: the image head)
+        return any(k in n for k in KERNELS) or ("conv_kernel<" in n and n.split(">(")[0].endswith(", 0"))
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == name and is3(r["Kernel_Name"])]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     return [float(r["Counter_Value"]) * 1024 for r in rows]
 fetch, write = counters(sys.argv[1], "FETCH_SIZE"), counters(sys.argv[2], "WRITE_SIZE")

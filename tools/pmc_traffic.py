@@ -12,7 +12,10 @@ tot = collections.defaultdict(float); n = collections.defaultdict(set)
 for cname, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     for f in glob.glob(os.path.join(root, sub, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            if not any(k in r["Kernel_Name"] for k in ("conv3s_kernel", "conv3p_kernel", "conv3w_kernel", "conv3r_kernel", "conv3t_kernel")) or r["Counter_Name"] != cname: continue
+            # (the 3x3 family: the persistent kernels, and conv_kernel in its CONV3 mode -- template argument MODE = 0: the image head)
+            k3 = any(k in r["Kernel_Name"] for k in ("conv3s_kernel", "conv3p_kernel", "conv3w_kernel", "conv3r_kernel", "conv3t_kernel")) or \
+                 ("conv_kernel<" in r["Kernel_Name"] and r["Kernel_Name"].split(">(")[0].endswith(", 0"))
+            if not k3 or r["Counter_Name"] != cname: continue
             tot[cname] += float(r["Counter_Value"]); n[cname].add(r["Dispatch_Id"])
 launches = len(n["FETCH_SIZE"]) or 1
 fetch = 2.0 * tot["FETCH_SIZE"] * 1024 / launches
